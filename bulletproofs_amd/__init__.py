@@ -1,0 +1,13 @@
+"""bulletproofs_amd — Python harness over libbpmsm.so (HIP kernels + C ABI, include/bpmsm.h).
+
+The product is the shared library; this package only binds it with ctypes for the tests and
+bench.py.  There is no CPU fallback: importing works anywhere (the library is loaded lazily), but
+any compute call raises if libbpmsm.so is missing or no HIP device is present.
+"""
+from ._lib import (  # noqa: F401
+    BpError,
+    Context,
+    lib,
+    lib_path,
+    EXPORTED_SYMBOLS,
+)

@@ -1,0 +1,111 @@
+"""ctypes binding of include/bpmsm.h."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+BP_OK = 0
+BP_EINVAL, BP_EPOINT, BP_EHIP, BP_ERCCL, BP_ENOMEM = -1, -2, -3, -4, -5
+
+# every symbol include/bpmsm.h declares (tests/test_abi.py checks the header against this list
+# and the loaded library against both)
+EXPORTED_SYMBOLS = [
+    "bp_ctx_create",
+    "bp_ctx_destroy",
+    "bp_last_error",
+    "bp_device_count",
+    "bp_msm",
+    "bp_msm_device",
+    "bp_msm_set_window",
+]
+
+
+class BpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("bpmsm error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "libbpmsm.so")
+
+
+_lib = None
+
+
+def lib():
+    """Load libbpmsm.so (built in-tree by `make -C bulletproofs_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise BpError(BP_EHIP, "libbpmsm.so not built (%s); run __graft_entry__.build() — there is no CPU fallback" % path)
+    L = ctypes.CDLL(path)
+    vp, cp, sz, i32 = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int
+    L.bp_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
+    L.bp_ctx_create.restype = i32
+    L.bp_ctx_destroy.argtypes = [vp]
+    L.bp_ctx_destroy.restype = None
+    L.bp_last_error.argtypes = []
+    L.bp_last_error.restype = cp
+    L.bp_device_count.argtypes = []
+    L.bp_device_count.restype = i32
+    L.bp_msm.argtypes = [vp, cp, cp, sz, cp, cp]
+    L.bp_msm.restype = i32
+    L.bp_msm_device.argtypes = [vp, vp, vp, sz, cp, cp]
+    L.bp_msm_device.restype = i32
+    L.bp_msm_set_window.argtypes = [vp, i32]
+    L.bp_msm_set_window.restype = None
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != BP_OK:
+        raise BpError(rc, lib().bp_last_error().decode(errors="replace"))
+
+
+class Context:
+    """`bp_ctx`: one HIP stream + workspaces on one device."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        _check(lib().bp_ctx_create(device, ctypes.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().bp_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_window(self, c):
+        lib().bp_msm_set_window(self._h, c)
+
+    def msm(self, points_xy, scalars_be, init_xy=None):
+        """out = init + sum scalars[i]*points[i]; bytes in, 64 bytes out (see include/bpmsm.h)."""
+        points_xy, scalars_be = bytes(points_xy), bytes(scalars_be)
+        n = len(scalars_be) // 32
+        if len(points_xy) != 64 * n or len(scalars_be) != 32 * n:
+            raise BpError(BP_EINVAL, "points/scalars length mismatch")
+        out = ctypes.create_string_buffer(64)
+        _check(lib().bp_msm(self._h, points_xy, scalars_be, n, init_xy, out))
+        return out.raw
+
+    def msm_device(self, d_points, d_scalars, n, init_xy=None):
+        """Same with device pointers (ints), e.g. torch tensors' data_ptr()."""
+        out = ctypes.create_string_buffer(64)
+        _check(lib().bp_msm_device(self._h, ctypes.c_void_p(d_points), ctypes.c_void_p(d_scalars), n, init_xy, out))
+        return out.raw

@@ -1,0 +1,206 @@
+// secp256k1 point arithmetic (y^2 = x^3 + 7) in XYZZ coordinates: x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2.
+//
+// Replaces `Point<Secp256k1>` `+`, `-`, `*` of curv-kzen (call sites: every fold idiom of SURVEY.md
+// §2.2, e.g. /root/reference/src/proofs/range_proof.rs:770-774).  XYZZ is chosen because the MSM
+// hot loop is affine-into-accumulator additions: 8M + 2S (mixed) against 11M + 5S... for Jacobian
+// full adds, with no inversion until the very end.  Infinity is ZZ == 0.
+//
+// The reference's generator recipe makes h_vec[i] == g_vec[i+n] (range_proof.rs:837-841), so equal
+// and opposite operands DO occur inside one accumulator: every add handles P+P and P+(-P).
+#pragma once
+#include "fp.h"
+
+namespace bp {
+
+struct affine {  // 64 bytes; infinity is encoded as x = y = 0 (not a curve point since b = 7)
+    fp x, y;
+};
+struct xyzz {
+    fp X, Y, ZZ, ZZZ;
+};
+
+BP_HD bool affine_is_inf(const affine& p) { return fp_is_zero(p.x) && fp_is_zero(p.y); }
+BP_HD affine affine_inf() {
+    affine r;
+    r.x = fp_zero();
+    r.y = fp_zero();
+    return r;
+}
+BP_HD affine affine_neg(const affine& p) {
+    affine r;
+    r.x = p.x;
+    r.y = fp_neg(p.y);
+    return r;
+}
+BP_HD bool affine_eq(const affine& a, const affine& b) { return fp_eq(a.x, b.x) && fp_eq(a.y, b.y); }
+
+BP_HD bool xyzz_is_inf(const xyzz& p) { return fp_is_zero(p.ZZ); }
+BP_HD xyzz xyzz_inf() {
+    xyzz r;
+    r.X = fp_zero();
+    r.Y = fp_one();
+    r.ZZ = fp_zero();
+    r.ZZZ = fp_zero();
+    return r;
+}
+BP_HD xyzz xyzz_from_affine(const affine& p) {
+    xyzz r;
+    if (affine_is_inf(p)) return xyzz_inf();
+    r.X = p.x;
+    r.Y = p.y;
+    r.ZZ = fp_one();
+    r.ZZZ = fp_one();
+    return r;
+}
+BP_HD xyzz xyzz_neg(const xyzz& p) {
+    xyzz r = p;
+    r.Y = fp_neg(p.Y);
+    return r;
+}
+
+// dbl-2008-s-1 with a = 0: 6M + 3S.
+BP_HD xyzz xyzz_dbl(const xyzz& p) {
+    if (xyzz_is_inf(p) || fp_is_zero(p.Y)) return xyzz_inf();
+    xyzz r;
+    fp U = fp_dbl(p.Y);
+    fp V = fp_sqr(U);
+    fp W = fp_mul(U, V);
+    fp S = fp_mul(p.X, V);
+    fp XX = fp_sqr(p.X);
+    fp M = fp_add(fp_dbl(XX), XX);
+    r.X = fp_sub(fp_sqr(M), fp_dbl(S));
+    r.Y = fp_sub(fp_mul(M, fp_sub(S, r.X)), fp_mul(W, p.Y));
+    r.ZZ = fp_mul(V, p.ZZ);
+    r.ZZZ = fp_mul(W, p.ZZZ);
+    return r;
+}
+
+// doubling of an affine point (mdbl-2008-s-1): 2M + 3S... (ZZ = ZZZ = 1).
+BP_HD xyzz xyzz_dbl_affine(const affine& p) {
+    if (affine_is_inf(p) || fp_is_zero(p.y)) return xyzz_inf();
+    xyzz r;
+    fp U = fp_dbl(p.y);
+    fp V = fp_sqr(U);
+    fp W = fp_mul(U, V);
+    fp S = fp_mul(p.x, V);
+    fp XX = fp_sqr(p.x);
+    fp M = fp_add(fp_dbl(XX), XX);
+    r.X = fp_sub(fp_sqr(M), fp_dbl(S));
+    r.Y = fp_sub(fp_mul(M, fp_sub(S, r.X)), fp_mul(W, p.y));
+    r.ZZ = V;
+    r.ZZZ = W;
+    return r;
+}
+
+// acc += p (p affine, not infinity-checked by callers that skip zero digits): madd-2008-s, 8M + 2S.
+BP_HD void xyzz_madd(xyzz& acc, const affine& p) {
+    if (affine_is_inf(p)) return;
+    if (xyzz_is_inf(acc)) {
+        acc = xyzz_from_affine(p);
+        return;
+    }
+    fp U2 = fp_mul(p.x, acc.ZZ);
+    fp S2 = fp_mul(p.y, acc.ZZZ);
+    fp Pd = fp_sub(U2, acc.X);
+    fp R = fp_sub(S2, acc.Y);
+    if (fp_is_zero(Pd)) {
+        if (fp_is_zero(R))
+            acc = xyzz_dbl_affine(p);
+        else
+            acc = xyzz_inf();
+        return;
+    }
+    fp PP = fp_sqr(Pd);
+    fp PPP = fp_mul(Pd, PP);
+    fp Qv = fp_mul(acc.X, PP);
+    fp X3 = fp_sub(fp_sub(fp_sqr(R), PPP), fp_dbl(Qv));
+    fp Y3 = fp_sub(fp_mul(R, fp_sub(Qv, X3)), fp_mul(acc.Y, PPP));
+    acc.X = X3;
+    acc.Y = Y3;
+    acc.ZZ = fp_mul(acc.ZZ, PP);
+    acc.ZZZ = fp_mul(acc.ZZZ, PPP);
+}
+
+// acc += q (both XYZZ): add-2008-s, 12M + 2S.
+BP_HD void xyzz_add(xyzz& acc, const xyzz& q) {
+    if (xyzz_is_inf(q)) return;
+    if (xyzz_is_inf(acc)) {
+        acc = q;
+        return;
+    }
+    fp U1 = fp_mul(acc.X, q.ZZ);
+    fp U2 = fp_mul(q.X, acc.ZZ);
+    fp S1 = fp_mul(acc.Y, q.ZZZ);
+    fp S2 = fp_mul(q.Y, acc.ZZZ);
+    fp Pd = fp_sub(U2, U1);
+    fp R = fp_sub(S2, S1);
+    if (fp_is_zero(Pd)) {
+        if (fp_is_zero(R))
+            acc = xyzz_dbl(acc);
+        else
+            acc = xyzz_inf();
+        return;
+    }
+    fp PP = fp_sqr(Pd);
+    fp PPP = fp_mul(Pd, PP);
+    fp Qv = fp_mul(U1, PP);
+    fp X3 = fp_sub(fp_sub(fp_sqr(R), PPP), fp_dbl(Qv));
+    fp Y3 = fp_sub(fp_mul(R, fp_sub(Qv, X3)), fp_mul(S1, PPP));
+    acc.X = X3;
+    acc.Y = Y3;
+    acc.ZZ = fp_mul(fp_mul(acc.ZZ, q.ZZ), PP);
+    acc.ZZZ = fp_mul(fp_mul(acc.ZZZ, q.ZZZ), PPP);
+}
+
+// Canonical affine form (one field inversion): the group element the reference would hold.
+BP_HD affine xyzz_to_affine(const xyzz& p) {
+    if (xyzz_is_inf(p)) return affine_inf();
+    // 1/ZZZ; then 1/ZZ = ZZ^2 / ZZZ^2 ... use: zi3 = 1/ZZZ, zi2 = (ZZ * zi3)^2 since ZZ^3 = ZZZ^2 => ZZ/ZZZ = 1/Z
+    fp zi3 = fp_inv(p.ZZZ);
+    fp zi = fp_mul(p.ZZ, zi3);
+    fp zi2 = fp_sqr(zi);
+    affine r;
+    r.x = fp_mul(p.X, zi2);
+    r.y = fp_mul(p.Y, zi3);
+    return r;
+}
+
+// y^2 == x^3 + 7 ?
+BP_HD bool affine_on_curve(const affine& p) {
+    fp rhs = fp_mul(fp_sqr(p.x), p.x);
+    fp seven = fp_zero();
+    seven.v[0] = 7;
+    rhs = fp_add(rhs, seven);
+    return fp_eq(fp_sqr(p.y), rhs);
+}
+
+// 33-byte SEC1 compressed -> affine (curv `Point::from_bytes`); false if not a curve point.
+BP_HD bool affine_decompress(affine& out, const uint8_t* b33) {
+    if (b33[0] != 2 && b33[0] != 3) return false;
+    fp x = fp_from_be(b33 + 1);
+    if (!fp_is_canonical(x)) return false;
+    fp rhs = fp_mul(fp_sqr(x), x);
+    fp seven = fp_zero();
+    seven.v[0] = 7;
+    rhs = fp_add(rhs, seven);
+    fp y = fp_sqrt_candidate(rhs);
+    if (!fp_eq(fp_sqr(y), rhs)) return false;
+    if ((y.v[0] & 1u) != (uint32_t)(b33[0] & 1u)) y = fp_neg(y);
+    out.x = x;
+    out.y = y;
+    return true;
+}
+
+// boundary encoding: x||y big-endian, 64 zero bytes = infinity (include/bpmsm.h)
+BP_HD void affine_to_be64(uint8_t* b, const affine& p) {
+    fp_to_be(b, p.x);
+    fp_to_be(b + 32, p.y);
+}
+BP_HD affine affine_from_be64(const uint8_t* b) {
+    affine r;
+    r.x = fp_from_be(b);
+    r.y = fp_from_be(b + 32);
+    return r;
+}
+
+}  // namespace bp

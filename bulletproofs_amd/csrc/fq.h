@@ -1,0 +1,201 @@
+// secp256k1 scalar field F_q (group order q) on 8 x 32-bit limbs, Montgomery form (R = 2^256).
+//
+// Replaces curv-kzen's `Scalar<Secp256k1>` / `BigInt::mod_{add,sub,mul,inv,pow}` arithmetic used to
+// derive the verifier's scalar vector (/root/reference/src/proofs/range_proof.rs:565-740,
+// inner_product.rs:276-317, range_proof_wip.rs:419-574).  q is not pseudo-Mersenne, so products use
+// a CIOS Montgomery multiply (64 + 64 + 8 `v_mad_u64_u32`) as north_star prescribes.  `fq` values
+// are plain integers in [0, q); `fqm` values are in the Montgomery domain.  Conversions are
+// explicit so the canonical 32-byte big-endian scalars at the boundary are bit-identical to the
+// reference's.
+#pragma once
+#include "fp.h"
+
+namespace bp {
+
+struct fq {
+    uint32_t v[8];
+};
+
+#define BP_Q_LIMBS {0xd0364141u, 0xbfd25e8cu, 0xaf48a03bu, 0xbaaedce6u, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu}
+#define BP_Q_INV32 0x5588b13fu /* -q^-1 mod 2^32 */
+
+BP_HD uint32_t fq_q(int i) {
+    const uint32_t q[8] = BP_Q_LIMBS;
+    return q[i];
+}
+BP_HD fq fq_zero() {
+    fq r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = 0;
+    return r;
+}
+BP_HD fq fq_from_u32(uint32_t x) {
+    fq r = fq_zero();
+    r.v[0] = x;
+    return r;
+}
+BP_HD bool fq_is_zero(const fq& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.v[i];
+    return o == 0;
+}
+BP_HD bool fq_eq(const fq& a, const fq& b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+}
+// r = a - q; returns borrow (1 if a < q).
+BP_HD uint32_t fq_sub_q(uint32_t r[8], const uint32_t a[8]) {
+    const uint32_t q[8] = BP_Q_LIMBS;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (int64_t)a[i] - (int64_t)q[i];
+        r[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return (uint32_t)(c & 1);
+}
+// value = carry*2^256 + r < 2q  ->  r mod q
+BP_HD void fq_final_reduce(uint32_t r[8], uint32_t carry) {
+    uint32_t s[8];
+    uint32_t borrow = fq_sub_q(s, r);
+    if (carry | (borrow ^ 1u)) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) r[i] = s[i];
+    }
+}
+BP_HD fq fq_add(const fq& a, const fq& b) {
+    fq r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)a.v[i] + b.v[i];
+        r.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    fq_final_reduce(r.v, (uint32_t)c);
+    return r;
+}
+BP_HD fq fq_sub(const fq& a, const fq& b) {
+    const uint32_t q[8] = BP_Q_LIMBS;
+    fq r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (int64_t)a.v[i] - (int64_t)b.v[i];
+        r.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    if (c) {
+        uint64_t d = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            d += (uint64_t)r.v[i] + q[i];
+            r.v[i] = (uint32_t)d;
+            d >>= 32;
+        }
+    }
+    return r;
+}
+BP_HD fq fq_neg(const fq& a) { return fq_sub(fq_zero(), a); }
+
+// Montgomery product a*b*R^-1 mod q (CIOS).  Inputs < q.
+BP_HD fq fq_mont_mul(const fq& a, const fq& b) {
+    const uint32_t q[8] = BP_Q_LIMBS;
+    uint32_t t[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (uint64_t)a.v[i] * b.v[j] + t[j];
+            t[j] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[8] = (uint32_t)c;
+        t[9] = (uint32_t)(c >> 32);
+        uint32_t m = t[0] * BP_Q_INV32;
+        c = (uint64_t)m * q[0] + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            c += (uint64_t)m * q[j] + t[j];
+            t[j - 1] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[7] = (uint32_t)c;
+        t[8] = t[9] + (uint32_t)(c >> 32);
+    }
+    fq r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    fq_final_reduce(r.v, t[8]);
+    return r;
+}
+
+BP_HD fq fq_R2() {
+    fq r = {{0x67d7d140u, 0x896cf214u, 0x0e7cf878u, 0x741496c2u, 0x5bcd07c6u, 0xe697f5e4u, 0x81c69bc5u, 0x9d671cd5u}};
+    return r;
+}
+BP_HD fq fq_mont_one() {  // R mod q
+    fq r = {{0x2fc9bebfu, 0x402da173u, 0x50b75fc4u, 0x45512319u, 0x00000001u, 0, 0, 0}};
+    return r;
+}
+BP_HD fq fq_to_mont(const fq& a) { return fq_mont_mul(a, fq_R2()); }
+BP_HD fq fq_from_mont(const fq& a) { return fq_mont_mul(a, fq_from_u32(1)); }
+
+// Plain-domain product a*b mod q (two Montgomery multiplies); for the host protocol layer.
+BP_HD fq fq_mul(const fq& a, const fq& b) { return fq_mont_mul(fq_mont_mul(a, b), fq_R2()); }
+
+// a^(q-2) in the Montgomery domain (input and output in Montgomery form). a != 0.
+BP_HD_NOINLINE fq fq_mont_inv(fq a) {
+    const uint32_t e[8] = {0xd036413fu, 0xbfd25e8cu, 0xaf48a03bu, 0xbaaedce6u, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    fq acc = fq_mont_one();
+    for (int i = 255; i >= 0; i--) {
+        acc = fq_mont_mul(acc, acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = fq_mont_mul(acc, a);
+    }
+    return acc;
+}
+BP_HD fq fq_inv(const fq& a) { return fq_from_mont(fq_mont_inv(fq_to_mont(a))); }
+
+// 32 big-endian bytes -> scalar reduced mod q (`Scalar::from(&BigInt)` for 256-bit inputs).
+BP_HD fq fq_from_be_reduce(const uint8_t* b) {
+    fq r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint8_t* p = b + 4 * (7 - i);
+        r.v[i] = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+    }
+    fq_final_reduce(r.v, 0);  // 2^256 < 2q, one conditional subtraction suffices
+    return r;
+}
+// true iff the 32 bytes encode a value < q (curv `Scalar::from_bytes` acceptance, zero allowed).
+BP_HD bool fq_be_is_canonical(const uint8_t* b) {
+    uint32_t a[8], s[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint8_t* p = b + 4 * (7 - i);
+        a[i] = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+    }
+    return fq_sub_q(s, a) == 1;
+}
+BP_HD void fq_to_be(uint8_t* b, const fq& a) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint8_t* p = b + 4 * (7 - i);
+        p[0] = (uint8_t)(a.v[i] >> 24);
+        p[1] = (uint8_t)(a.v[i] >> 16);
+        p[2] = (uint8_t)(a.v[i] >> 8);
+        p[3] = (uint8_t)(a.v[i]);
+    }
+}
+
+}  // namespace bp

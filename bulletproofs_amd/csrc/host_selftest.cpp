@@ -1,0 +1,66 @@
+// CPU-side unit-test hooks for the __host__ __device__ arithmetic headers (fp.h, fq.h, ec.h,
+// sha256.h).  Built with g++ into bulletproofs_amd/libbpmsm_hosttest.so and driven through ctypes
+// by tests/test_host_arith.py (no GPU needed).  Not part of the product ABI.
+#include <string.h>
+
+#include "ec.h"
+#include "fq.h"
+#include "sha256.h"
+
+using namespace bp;
+
+extern "C" {
+
+void bpt_fp_mul(uint8_t* out, const uint8_t* a, const uint8_t* b) { fp_to_be(out, fp_mul(fp_from_be(a), fp_from_be(b))); }
+void bpt_fp_sqr(uint8_t* out, const uint8_t* a) { fp_to_be(out, fp_sqr(fp_from_be(a))); }
+void bpt_fp_add(uint8_t* out, const uint8_t* a, const uint8_t* b) { fp_to_be(out, fp_add(fp_from_be(a), fp_from_be(b))); }
+void bpt_fp_sub(uint8_t* out, const uint8_t* a, const uint8_t* b) { fp_to_be(out, fp_sub(fp_from_be(a), fp_from_be(b))); }
+void bpt_fp_inv(uint8_t* out, const uint8_t* a) { fp_to_be(out, fp_inv(fp_from_be(a))); }
+void bpt_fp_sqrt(uint8_t* out, const uint8_t* a) { fp_to_be(out, fp_sqrt_candidate(fp_from_be(a))); }
+
+static fq fq_from_be_raw(const uint8_t* b) { return fq_from_be_reduce(b); }
+void bpt_fq_mul(uint8_t* out, const uint8_t* a, const uint8_t* b) { fq_to_be(out, fq_mul(fq_from_be_raw(a), fq_from_be_raw(b))); }
+void bpt_fq_add(uint8_t* out, const uint8_t* a, const uint8_t* b) { fq_to_be(out, fq_add(fq_from_be_raw(a), fq_from_be_raw(b))); }
+void bpt_fq_sub(uint8_t* out, const uint8_t* a, const uint8_t* b) { fq_to_be(out, fq_sub(fq_from_be_raw(a), fq_from_be_raw(b))); }
+void bpt_fq_inv(uint8_t* out, const uint8_t* a) { fq_to_be(out, fq_inv(fq_from_be_raw(a))); }
+void bpt_fq_reduce(uint8_t* out, const uint8_t* a) { fq_to_be(out, fq_from_be_raw(a)); }
+
+// out = a + b through XYZZ (mixed add), normalised
+void bpt_ec_madd(uint8_t* out, const uint8_t* a, const uint8_t* b) {
+    xyzz acc = xyzz_from_affine(affine_from_be64(a));
+    xyzz_madd(acc, affine_from_be64(b));
+    affine_to_be64(out, xyzz_to_affine(acc));
+}
+// out = (a + a) + b with a full XYZZ add of two non-trivial Z operands, normalised
+void bpt_ec_dbl_add(uint8_t* out, const uint8_t* a, const uint8_t* b) {
+    xyzz da = xyzz_dbl(xyzz_from_affine(affine_from_be64(a)));
+    xyzz db = xyzz_dbl_affine(affine_from_be64(b));
+    xyzz_madd(db, affine_neg(affine_from_be64(b)));  // db = b (non-trivial ZZ)
+    xyzz_add(da, db);
+    affine_to_be64(out, xyzz_to_affine(da));
+}
+// out = k * a (double-and-add through XYZZ), normalised
+void bpt_ec_mul(uint8_t* out, const uint8_t* a, const uint8_t* k) {
+    affine p = affine_from_be64(a);
+    xyzz acc = xyzz_inf();
+    for (int i = 0; i < 256; i++) {
+        acc = xyzz_dbl(acc);
+        if ((k[i / 8] >> (7 - (i % 8))) & 1) xyzz_madd(acc, p);
+    }
+    affine_to_be64(out, xyzz_to_affine(acc));
+}
+int bpt_ec_decompress(uint8_t* out, const uint8_t* in33) {
+    affine p;
+    if (!affine_decompress(p, in33)) return -1;
+    affine_to_be64(out, p);
+    return 0;
+}
+int bpt_ec_on_curve(const uint8_t* a) { return affine_on_curve(affine_from_be64(a)) ? 1 : 0; }
+
+void bpt_sha256(uint8_t* out, const uint8_t* data, uint32_t len) {
+    sha256_ctx c;
+    sha256_init(c);
+    sha256_update(c, data, len);
+    sha256_final(c, out);
+}
+}

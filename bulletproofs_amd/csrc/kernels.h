@@ -1,0 +1,21 @@
+// Host-callable launchers of the HIP kernels (defined in the .hip files of this directory).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ec.h"
+
+namespace bp {
+
+// msm_kernels.hip
+size_t msm_slice_lds_bytes(int c, int M, int T);
+hipError_t launch_ingest_points(const uint8_t* in_be, affine* out, size_t n, int* err, hipStream_t st);
+hipError_t launch_export_points(const affine* in, uint8_t* out_be, size_t n, hipStream_t st);
+hipError_t launch_scalars_to_digits(const uint8_t* scalars_be, size_t n, size_t npad, int c, int W, int16_t* digits, hipStream_t st);
+hipError_t launch_msm_slice(const affine* pts, const int16_t* digits, size_t n, size_t npad, int M, int c, int W, int S, int T, xyzz* partial,
+                            hipStream_t st);
+hipError_t launch_msm_reduce_slices(const xyzz* partial, int S, int W, xyzz* wsum, hipStream_t st);
+hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine* init, affine* out_limbs, uint8_t* out_be, hipStream_t st);
+
+}  // namespace bp

@@ -1,0 +1,319 @@
+// Pippenger bucket MSM for secp256k1 on CDNA4 (gfx950) — generic (variable-base) path.
+//
+// Replaces the reference's fold idiom
+//     (0..n).map(|i| &points[i] * &Scalar::from(&scalars[i])).fold(init, |acc, x| acc + x)
+// (/root/reference/src/proofs/range_proof.rs:116-122, 236-244, 770-774; inner_product.rs:73-115,
+// 336-338; range_proof_wip.rs:249-251, 370-372, 598-602; weighted_inner_product.rs:109-154, 500-504)
+// with: signed-digit recoding -> per-(slice, window) workgroups that counting-sort their points by
+// bucket in LDS and sum each bucket in registers (no atomics on group elements, no global sort)
+// -> in-LDS suffix-scan bucket reduction -> per-window slice reduction -> Horner combine.
+//
+// Data layout in HBM: points as `affine` (16 x u32 limbs, 64 B, one cache line per gather);
+// digits as int16 [W][Npad] (window-major so a (slice, window) workgroup streams a contiguous,
+// coalesced run); partial sums as XYZZ (128 B).
+#include <hip/hip_runtime.h>
+
+#include "ec.h"
+#include "fq.h"
+#include "kernels.h"
+
+namespace bp {
+
+// ---------------------------------------------------------------------------------------------
+// ingest: 64-byte big-endian x||y -> limb form, with the on-curve check curv's Point::from_bytes
+// performs.  err: bit 0 set if any point is neither infinity (64 zero bytes) nor on the curve.
+__global__ void k_ingest_points(const uint8_t* __restrict__ in_be, affine* __restrict__ out, size_t n, int* err) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(in_be + 64 * i);
+    affine p;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        p.x.v[k] = __builtin_bswap32(src[7 - k]);
+        p.y.v[k] = __builtin_bswap32(src[15 - k]);
+    }
+    bool ok = affine_is_inf(p) || (fp_is_canonical(p.x) && fp_is_canonical(p.y) && affine_on_curve(p));
+    if (!ok) atomicOr(err, 1);
+    out[i] = p;
+}
+
+// limb form -> 64-byte big-endian (infinity -> 64 zero bytes)
+__global__ void k_export_points(const affine* __restrict__ in, uint8_t* __restrict__ out_be, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    affine p = in[i];
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out_be + 64 * i);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        dst[7 - k] = __builtin_bswap32(p.x.v[k]);
+        dst[15 - k] = __builtin_bswap32(p.y.v[k]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scalars (32 B big-endian, any 256-bit value; reduced mod q like `Scalar::from(&BigInt)`) ->
+// signed c-bit digits d_w in [-(2^(c-1)-1), 2^(c-1)], W = 256/c + 1 windows, window-major.
+__device__ __forceinline__ void recode_signed(const uint32_t k[8], int c, int W, int16_t* __restrict__ out, size_t stride) {
+    uint32_t carry = 0;
+    const uint32_t half = 1u << (c - 1);
+    const uint32_t mask = (1u << c) - 1;
+    for (int w = 0; w < W; w++) {
+        int bit = w * c;
+        uint32_t v = 0;
+        if (bit < 256) {
+            int limb = bit >> 5, sh = bit & 31;
+            uint64_t two = k[limb];
+            if (limb + 1 < 8) two |= (uint64_t)k[limb + 1] << 32;
+            v = (uint32_t)(two >> sh) & mask;
+        }
+        v += carry;
+        int d;
+        if (v > half) {
+            d = (int)v - (int)(1u << c);
+            carry = 1;
+        } else {
+            d = (int)v;
+            carry = 0;
+        }
+        out[(size_t)w * stride] = (int16_t)d;
+    }
+}
+
+__global__ void k_scalars_to_digits(const uint8_t* __restrict__ scalars_be, size_t n, size_t npad, int c, int W, int16_t* __restrict__ digits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    if (i >= n) {
+        for (int w = 0; w < W; w++) digits[(size_t)w * npad + i] = 0;
+        return;
+    }
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(scalars_be + 32 * i);
+    fq k;
+#pragma unroll
+    for (int j = 0; j < 8; j++) k.v[j] = __builtin_bswap32(src[7 - j]);
+    fq_final_reduce(k.v, 0);
+    recode_signed(k.v, c, W, digits + i, npad);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One workgroup per (slice of <= M points, window w).
+//   1. LDS histogram of |digit| (ds_add), exclusive scan, scatter of 16-bit local indices
+//      (bit 15 = negate) -> points of this slice sorted by bucket, in LDS.
+//   2. Thread t owns the r = NB/T consecutive buckets [t*r, (t+1)*r): sums each bucket in
+//      registers (mixed adds from gathered 64-B points), folding them high-to-low into
+//      run = sum B_b and tot = sum (b - t*r + 1) B_b.
+//   3. Block result sum_b (b+1) B_b = sum_t tot_t + sum_{u>=1} suffix_u(r * run_t): an in-LDS
+//      Hillis-Steele suffix scan followed by a tree reduction (r is a power of two -> doublings).
+// LDS: 2*(NB+1) u32 + M u16 + T XYZZ.
+template <int T>
+__global__ __launch_bounds__(T) void k_msm_slice(const affine* __restrict__ pts, const int16_t* __restrict__ digits, size_t n, size_t npad,
+                                                 int M, int c, xyzz* __restrict__ partial /* [W][S] */) {
+    extern __shared__ __align__(16) uint8_t smem_raw[];
+    const int NB = 1 << (c - 1);
+    xyzz* red = reinterpret_cast<xyzz*>(smem_raw);                   // T
+    uint32_t* start = reinterpret_cast<uint32_t*>(red + T);          // NB + 1
+    uint32_t* cursor = start + (NB + 1);                             // NB + 1
+    uint16_t* sorted = reinterpret_cast<uint16_t*>(cursor + (NB + 1));  // M
+
+    const int tid = threadIdx.x;
+    const int slice = blockIdx.x, w = blockIdx.y, S = gridDim.x;
+    const size_t base = (size_t)slice * M;
+    const int len = (int)((n - base) < (size_t)M ? (n - base) : (size_t)M);
+    const int16_t* dg = digits + (size_t)w * npad + base;
+
+    for (int b = tid; b <= NB; b += T) cursor[b] = 0;
+    __syncthreads();
+    for (int i = tid; i < len; i += T) {
+        int d = dg[i];
+        if (d != 0) atomicAdd(&cursor[(d < 0 ? -d : d) - 1], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of cursor[0..NB) -> start[0..NB]; chunked: each thread scans `per` entries
+    {
+        const int per = (NB + T - 1) / T;
+        int lo = tid * per, hi = lo + per;
+        if (hi > NB) hi = NB;
+        uint32_t s = 0;
+        for (int b = lo; b < hi; b++) s += cursor[b];
+        uint32_t* tsum = reinterpret_cast<uint32_t*>(red);  // T u32, reuse
+        tsum[tid] = s;
+        __syncthreads();
+        for (int off = 1; off < T; off <<= 1) {
+            uint32_t v = tsum[tid];
+            uint32_t a = (tid >= off) ? tsum[tid - off] : 0;
+            __syncthreads();
+            tsum[tid] = v + a;
+            __syncthreads();
+        }
+        uint32_t run = tsum[tid] - s;  // exclusive prefix of this thread's chunk
+        for (int b = lo; b < hi; b++) {
+            uint32_t cn = cursor[b];
+            start[b] = run;
+            cursor[b] = run;
+            run += cn;
+        }
+        if (hi == NB && lo < NB) start[NB] = run;
+        __syncthreads();
+    }
+    for (int i = tid; i < len; i += T) {
+        int d = dg[i];
+        if (d != 0) {
+            uint32_t pos = atomicAdd(&cursor[(d < 0 ? -d : d) - 1], 1u);
+            sorted[pos] = (uint16_t)(i | (d < 0 ? 0x8000 : 0));
+        }
+    }
+    __syncthreads();
+
+    // bucket accumulation
+    const int Tact = NB < T ? NB : T;
+    const int r = NB / Tact;  // power of two
+    xyzz run = xyzz_inf(), tot = xyzz_inf();
+    if (tid < Tact) {
+        for (int b = (tid + 1) * r - 1; b >= tid * r; b--) {
+            xyzz B = xyzz_inf();
+            uint32_t j0 = start[b], j1 = start[b + 1];
+            for (uint32_t j = j0; j < j1; j++) {
+                uint32_t e = sorted[j];
+                affine p = pts[base + (e & 0x7fff)];
+                if (e & 0x8000) p.y = fp_neg(p.y);
+                xyzz_madd(B, p);
+            }
+            xyzz_add(run, B);
+            xyzz_add(tot, run);
+        }
+        // r * run
+        for (int k = 1; k < r; k <<= 1) run = xyzz_dbl(run);
+    }
+    __syncthreads();  // tsum alias of red[] no longer needed
+    red[tid] = run;
+    __syncthreads();
+    // inclusive suffix scan: red[t] = sum_{u >= t} r*run_u
+    for (int off = 1; off < T; off <<= 1) {
+        xyzz v = red[tid];
+        bool has = tid + off < T;
+        xyzz o;
+        if (has) o = red[tid + off];
+        __syncthreads();
+        if (has) {
+            xyzz_add(v, o);
+            red[tid] = v;
+        }
+        __syncthreads();
+    }
+    // val_t = tot_t + (t >= 1 ? suffix_t : 0); tree-reduce
+    {
+        xyzz v = tot;
+        if (tid >= 1) {
+            xyzz s = red[tid];
+            xyzz_add(v, s);
+        }
+        __syncthreads();
+        red[tid] = v;
+        __syncthreads();
+    }
+    for (int off = T / 2; off >= 1; off >>= 1) {
+        if (tid < off) {
+            xyzz v = red[tid];
+            xyzz o = red[tid + off];
+            xyzz_add(v, o);
+            red[tid] = v;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) partial[(size_t)w * S + slice] = red[0];
+}
+
+template __global__ void k_msm_slice<64>(const affine*, const int16_t*, size_t, size_t, int, int, xyzz*);
+template __global__ void k_msm_slice<128>(const affine*, const int16_t*, size_t, size_t, int, int, xyzz*);
+template __global__ void k_msm_slice<256>(const affine*, const int16_t*, size_t, size_t, int, int, xyzz*);
+
+// ---------------------------------------------------------------------------------------------
+// wsum[w] = sum over slices of partial[w][s]; one 64-lane workgroup per window.
+__global__ __launch_bounds__(64) void k_msm_reduce_slices(const xyzz* __restrict__ partial, int S, xyzz* __restrict__ wsum) {
+    __shared__ xyzz red[64];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    xyzz acc = xyzz_inf();
+    for (int s = tid; s < S; s += 64) {
+        xyzz o = partial[(size_t)w * S + s];
+        xyzz_add(acc, o);
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int off = 32; off >= 1; off >>= 1) {
+        if (tid < off) {
+            xyzz v = red[tid];
+            xyzz o = red[tid + off];
+            xyzz_add(v, o);
+            red[tid] = v;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) wsum[w] = red[0];
+}
+
+// result = init + sum_w 2^(c*w) wsum[w]  (Horner, one lane: the doubling chain is inherently serial),
+// normalised to the canonical affine element and written as 64 big-endian bytes.
+__global__ void k_msm_horner(const xyzz* __restrict__ wsum, int W, int c, const affine* __restrict__ init, affine* __restrict__ out_limbs,
+                             uint8_t* __restrict__ out_be) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    xyzz acc = wsum[W - 1];
+    for (int w = W - 2; w >= 0; w--) {
+        for (int k = 0; k < c; k++) acc = xyzz_dbl(acc);
+        xyzz o = wsum[w];
+        xyzz_add(acc, o);
+    }
+    if (init) xyzz_madd(acc, *init);
+    affine a = xyzz_to_affine(acc);
+    if (out_limbs) *out_limbs = a;
+    if (out_be) {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(out_be);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            dst[7 - k] = __builtin_bswap32(a.x.v[k]);
+            dst[15 - k] = __builtin_bswap32(a.y.v[k]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launch helpers
+size_t msm_slice_lds_bytes(int c, int M, int T) {
+    int NB = 1 << (c - 1);
+    return (size_t)T * sizeof(xyzz) + (size_t)2 * (NB + 1) * 4 + (size_t)M * 2;
+}
+
+hipError_t launch_ingest_points(const uint8_t* in_be, affine* out, size_t n, int* err, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ingest_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in_be, out, n, err);
+    return hipGetLastError();
+}
+hipError_t launch_export_points(const affine* in, uint8_t* out_be, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_export_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out_be, n);
+    return hipGetLastError();
+}
+hipError_t launch_scalars_to_digits(const uint8_t* scalars_be, size_t n, size_t npad, int c, int W, int16_t* digits, hipStream_t st) {
+    hipLaunchKernelGGL(k_scalars_to_digits, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st, scalars_be, n, npad, c, W, digits);
+    return hipGetLastError();
+}
+hipError_t launch_msm_slice(const affine* pts, const int16_t* digits, size_t n, size_t npad, int M, int c, int W, int S, int T, xyzz* partial,
+                            hipStream_t st) {
+    size_t lds = msm_slice_lds_bytes(c, M, T);
+    dim3 grid((unsigned)S, (unsigned)W);
+    if (T == 64)
+        hipLaunchKernelGGL(k_msm_slice<64>, grid, dim3(64), lds, st, pts, digits, n, npad, M, c, partial);
+    else if (T == 128)
+        hipLaunchKernelGGL(k_msm_slice<128>, grid, dim3(128), lds, st, pts, digits, n, npad, M, c, partial);
+    else
+        hipLaunchKernelGGL(k_msm_slice<256>, grid, dim3(256), lds, st, pts, digits, n, npad, M, c, partial);
+    return hipGetLastError();
+}
+hipError_t launch_msm_reduce_slices(const xyzz* partial, int S, int W, xyzz* wsum, hipStream_t st) {
+    hipLaunchKernelGGL(k_msm_reduce_slices, dim3((unsigned)W), dim3(64), 0, st, partial, S, wsum);
+    return hipGetLastError();
+}
+hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine* init, affine* out_limbs, uint8_t* out_be, hipStream_t st) {
+    hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(64), 0, st, wsum, W, c, init, out_limbs, out_be);
+    return hipGetLastError();
+}
+
+}  // namespace bp

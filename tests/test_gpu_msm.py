@@ -1,0 +1,88 @@
+"""GPU parity: bp_msm (HIP Pippenger, through the C ABI) == oracle fold idiom, bit for bit."""
+import hashlib
+import random
+
+import pytest
+
+from oracle import ec
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_points(rng, n, oracle_c):
+    ks = [rng.randrange(1, ec.Q) for _ in range(n)]
+    return oracle_c.mul_batch([ec.G] * n, ks)
+
+
+def _pack(points, scalars):
+    return b"".join(ec.enc64(p) for p in points), b"".join((k % 2**256).to_bytes(32, "big") for k in scalars)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 17, 64, 146, 257, 700])
+def test_msm_matches_oracle(ctx, oracle_c, n):
+    rng = random.Random(1000 + n)
+    pts = _rand_points(rng, n, oracle_c)
+    ks = [rng.randrange(ec.Q) for _ in range(n)]
+    pb, sb = _pack(pts, ks)
+    init = oracle_c.mul(ec.G, 777)
+    want = oracle_c.msm_naive(pts, ks, init)
+    got = ctx.msm(pb, sb, ec.enc64(init))
+    assert got == ec.enc64(want)
+    got0 = ctx.msm(pb, sb, None)
+    assert got0 == ec.enc64(oracle_c.msm_naive(pts, ks, None))
+
+
+def test_msm_edge_scalars_and_points(ctx, oracle_c):
+    """zero scalars, q-1, unreduced scalars >= q, infinity points, duplicate and opposite points
+    (the reference recipe makes h_vec[i] == g_vec[i+n]: range_proof.rs:837-841)."""
+    rng = random.Random(5)
+    base = _rand_points(rng, 8, oracle_c)
+    pts = base + [base[0], ec.neg(base[1]), None, base[2], base[2]]
+    ks = [0, 1, ec.Q - 1, ec.Q, ec.Q + 5, 2**256 - 1, 2**255, 12345, 5, 7, 99, 2**200 + 1, ec.Q - (2**200 + 1)]
+    pb, sb = _pack(pts, ks)
+    want = oracle_c.msm_naive(pts, [k % ec.Q for k in ks], None)
+    assert ctx.msm(pb, sb, None) == ec.enc64(want)
+    # same point with equal scalars lands in the same bucket -> doubling inside a bucket
+    pts2 = [base[3]] * 6 + [ec.neg(base[3])] * 6
+    ks2 = [1234567] * 12
+    assert ctx.msm(*_pack(pts2, ks2), None) == b"\0" * 64
+    pts3 = [base[3]] * 5
+    assert ctx.msm(*_pack(pts3, [3] * 5), None) == ec.enc64(oracle_c.mul(base[3], 15))
+
+
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 9, 10, 11])
+def test_msm_all_window_widths(ctx, oracle_c, c):
+    rng = random.Random(c)
+    n = 300
+    pts = _rand_points(rng, n, oracle_c)
+    ks = [rng.randrange(ec.Q) for _ in range(n)]
+    want = ec.enc64(oracle_c.msm_naive(pts, ks, None))
+    ctx.set_window(c)
+    try:
+        assert ctx.msm(*_pack(pts, ks), None) == want
+    finally:
+        ctx.set_window(0)
+
+
+def test_msm_rejects_off_curve_point(ctx):
+    import bulletproofs_amd as bpa
+    bad = (1).to_bytes(32, "big") + (1).to_bytes(32, "big")
+    with pytest.raises(bpa.BpError) as e:
+        ctx.msm(bad, (3).to_bytes(32, "big"), None)
+    assert e.value.code == -2
+
+
+def test_msm_linearity_large(ctx, oracle_c):
+    """Size-independent property at a size the oracle cannot finish quickly:
+    MSM(P, a) + MSM(P, b) == MSM(P, a+b), and sum k_i (r_i G) == (sum k_i r_i) G."""
+    rng = random.Random(99)
+    n = 20000
+    rs = [rng.randrange(1, ec.Q) for _ in range(64)]
+    base = oracle_c.mul_batch([ec.G] * 64, rs)
+    idx = [rng.randrange(64) for _ in range(n)]
+    pts = [base[i] for i in idx]
+    a = [rng.randrange(ec.Q) for _ in range(n)]
+    pb, sb = _pack(pts, a)
+    got = ctx.msm(pb, sb, None)
+    want_scalar = sum(a[i] * rs[idx[i]] for i in range(n)) % ec.Q
+    assert got == ec.enc64(oracle_c.mul(ec.G, want_scalar))
