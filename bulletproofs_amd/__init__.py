@@ -7,6 +7,7 @@ any compute call raises if libbpmsm.so is missing or no HIP device is present.
 from ._lib import (  # noqa: F401
     BpError,
     Context,
+    Gens,
     lib,
     lib_path,
     EXPORTED_SYMBOLS,

@@ -17,6 +17,13 @@ EXPORTED_SYMBOLS = [
     "bp_msm",
     "bp_msm_device",
     "bp_msm_set_window",
+    "bp_gens_create",
+    "bp_gens_destroy",
+    "bp_gens_table_bytes",
+    "bp_rangeproof_verify_batch",
+    "bp_rangeproof_verify_batch_device",
+    "bp_ctx_sync",
+    "bp_verify_set_lanes",
 ]
 
 
@@ -57,6 +64,20 @@ def lib():
     L.bp_msm_device.restype = i32
     L.bp_msm_set_window.argtypes = [vp, i32]
     L.bp_msm_set_window.restype = None
+    L.bp_gens_create.argtypes = [vp, cp, cp, sz, cp, cp, i32, ctypes.POINTER(vp)]
+    L.bp_gens_create.restype = i32
+    L.bp_gens_destroy.argtypes = [vp]
+    L.bp_gens_destroy.restype = None
+    L.bp_gens_table_bytes.argtypes = [vp]
+    L.bp_gens_table_bytes.restype = sz
+    L.bp_rangeproof_verify_batch.argtypes = [vp, vp, i32, i32, cp, sz, cp, sz, cp]
+    L.bp_rangeproof_verify_batch.restype = i32
+    L.bp_rangeproof_verify_batch_device.argtypes = [vp, vp, i32, i32, vp, sz, vp, sz, vp]
+    L.bp_rangeproof_verify_batch_device.restype = i32
+    L.bp_ctx_sync.argtypes = [vp]
+    L.bp_ctx_sync.restype = i32
+    L.bp_verify_set_lanes.argtypes = [vp, i32]
+    L.bp_verify_set_lanes.restype = None
     _lib = L
     return L
 
@@ -109,3 +130,54 @@ class Context:
         out = ctypes.create_string_buffer(64)
         _check(lib().bp_msm_device(self._h, ctypes.c_void_p(d_points), ctypes.c_void_p(d_scalars), n, init_xy, out))
         return out.raw
+
+    def sync(self):
+        _check(lib().bp_ctx_sync(self._h))
+
+    def set_verify_lanes(self, lanes):
+        lib().bp_verify_set_lanes(self._h, lanes)
+
+    def rangeproof_verify_batch(self, gens, n_bits, m, proofs, coms_xy):
+        """`RangeProof::aggregated_verify` for len(proofs)//proof_len proofs -> list of verdict codes."""
+        proofs, coms_xy = bytes(proofs), bytes(coms_xy)
+        nm = n_bits * m
+        k = max(nm.bit_length() - 1, 0)
+        proof_len = 292 + 66 * k
+        nproofs = len(proofs) // proof_len if proof_len else 0
+        if nproofs * proof_len != len(proofs) or len(coms_xy) != nproofs * m * 64:
+            raise BpError(BP_EINVAL, "proofs/commitments length mismatch")
+        out = ctypes.create_string_buffer(max(nproofs, 1))
+        _check(lib().bp_rangeproof_verify_batch(self._h, gens._h, n_bits, m, proofs, proof_len, coms_xy, nproofs, out))
+        return list(out.raw[:nproofs])
+
+    def rangeproof_verify_batch_device(self, gens, n_bits, m, d_proofs, proof_len, d_coms, nproofs, d_verdicts):
+        """Asynchronous device-pointer variant (ints); call sync() before reading verdicts."""
+        _check(lib().bp_rangeproof_verify_batch_device(self._h, gens._h, n_bits, m, ctypes.c_void_p(d_proofs), proof_len,
+                                                       ctypes.c_void_p(d_coms), nproofs, ctypes.c_void_p(d_verdicts)))
+
+
+class Gens:
+    """`bp_gens`: g_vec, h_vec, G, H uploaded once and expanded into the fixed-base table."""
+
+    def __init__(self, ctx, g_xy, h_xy, G_xy, H_xy, window_bits=0):
+        g_xy, h_xy = bytes(g_xy), bytes(h_xy)
+        if len(g_xy) != len(h_xy) or len(g_xy) % 64:
+            raise BpError(BP_EINVAL, "g_vec/h_vec length mismatch")
+        self._h = ctypes.c_void_p()
+        self.nm = len(g_xy) // 64
+        _check(lib().bp_gens_create(ctx._h, g_xy, h_xy, self.nm, bytes(G_xy), bytes(H_xy), window_bits, ctypes.byref(self._h)))
+
+    @property
+    def table_bytes(self):
+        return lib().bp_gens_table_bytes(self._h)
+
+    def close(self):
+        if self._h:
+            lib().bp_gens_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -34,6 +34,7 @@ struct bp_ctx {
     hipStream_t stream = nullptr;
     int* d_err = nullptr;
     int forced_c = 0;
+    int verify_lanes = 0;
     std::mutex mu;
     bp::DevBuf in_points_be, in_scalars_be, points, digits, partial, wsum, result, initbuf;
     bp::DevBuf scratch[8];

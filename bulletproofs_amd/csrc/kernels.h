@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "ec.h"
+#include "fq.h"
 
 namespace bp {
 
@@ -17,5 +18,21 @@ hipError_t launch_msm_slice(const affine* pts, const int16_t* digits, size_t n, 
                             hipStream_t st);
 hipError_t launch_msm_reduce_slices(const xyzz* partial, int S, int W, xyzz* wsum, hipStream_t st);
 hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine* init, affine* out_limbs, uint8_t* out_be, hipStream_t st);
+
+
+// gens_kernels.hip
+hipError_t launch_gens_bases(const affine* pts, int np, int c, int W, xyzz* bases, hipStream_t st);
+hipError_t launch_xyzz_to_affine(const xyzz* in, affine* out, size_t n, hipStream_t st);
+hipError_t launch_gens_multiples(const affine* basesA, size_t nidx, int NB, xyzz* tmp, hipStream_t st);
+hipError_t launch_gens_normalize(const xyzz* tmp, size_t n, affine* table, hipStream_t st);
+
+// verify_kernels.hip
+hipError_t launch_bpv_decompress(const uint8_t* proofs, size_t proof_len, const uint8_t* coms_xy, int k, int m, size_t nproofs, affine* pts,
+                                 int* bad, hipStream_t st);
+hipError_t launch_bpv_scalars(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine* pts,
+                              const affine* gens, const affine* table, int c, int W, int16_t* digF, fq* varS, fq* sbuf, int* bad,
+                              hipStream_t st);
+hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine* pts, const affine* table, int c, int W,
+                          const int16_t* digF, const fq* varS, const int* bad, uint8_t* verdicts, hipStream_t st);
 
 }  // namespace bp

@@ -1,0 +1,214 @@
+// C ABI: generator tables (bp_gens) and the batched range-proof verifier.  Host plumbing only.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/bpmsm.h"
+#include "ctx.h"
+#include "kernels.h"
+
+using namespace bp;
+
+#define HIPCHK(expr, where)        \
+    do {                           \
+        hipError_t e__ = (expr);   \
+        if (e__ != hipSuccess) {   \
+            set_error(where, e__); \
+            return BP_EHIP;        \
+        }                          \
+    } while (0)
+
+struct bp_gens {
+    int device = 0;
+    size_t nm = 0;
+    int np = 0;       // 2nm + 2
+    int c = 0, W = 0, NB = 0;
+    affine* d_pts = nullptr;    // g_vec, h_vec, G, H (limb form)
+    affine* d_table = nullptr;  // [np][W][NB]
+    size_t table_bytes = 0;
+};
+
+static int pick_table_window(int np) {
+    // largest c in [4, 12] whose table (np * W * 2^(c-1) * 64 B) stays <= 512 MiB
+    int best = 4;
+    for (int c = 4; c <= 12; c++) {
+        size_t bytes = (size_t)np * (256 / c + 1) * ((size_t)1 << (c - 1)) * 64;
+        if (bytes <= ((size_t)512 << 20)) best = c;
+    }
+    return best;
+}
+
+extern "C" {
+
+int bp_gens_create(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t nm, const uint8_t G_xy[64], const uint8_t H_xy[64],
+                   int window_bits, bp_gens** out) {
+    if (!ctx || !out || !g_xy || !h_xy || !G_xy || !H_xy || nm == 0 || nm > (1u << 20)) return BP_EINVAL;
+    *out = nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t st = ctx->stream;
+    int np = (int)(2 * nm + 2);
+    int c = window_bits ? window_bits : pick_table_window(np);
+    if (c < 2 || c > 15) return BP_EINVAL;
+    int W = 256 / c + 1, NB = 1 << (c - 1);
+    bp_gens* g = new bp_gens();
+    g->device = ctx->device;
+    g->nm = nm;
+    g->np = np;
+    g->c = c;
+    g->W = W;
+    g->NB = NB;
+    size_t nidx = (size_t)np * W, nent = nidx * NB;
+    g->table_bytes = nent * sizeof(affine);
+    uint8_t* d_be = nullptr;
+    xyzz *d_bases = nullptr, *d_tmp = nullptr;
+    affine* d_basesA = nullptr;
+    int rc = BP_OK;
+    std::vector<uint8_t> host((size_t)np * 64);
+    memcpy(host.data(), g_xy, nm * 64);
+    memcpy(host.data() + nm * 64, h_xy, nm * 64);
+    memcpy(host.data() + 2 * nm * 64, G_xy, 64);
+    memcpy(host.data() + (2 * nm + 1) * 64, H_xy, 64);
+    for (int i = 0; i < np && rc == BP_OK; i++) {
+        bool allz = true;
+        for (int j = 0; j < 64; j++) allz = allz && host[(size_t)i * 64 + j] == 0;
+        if (allz) {
+            set_error_msg("generator is the point at infinity");
+            rc = BP_EPOINT;
+        }
+    }
+    hipError_t e = hipSuccess;
+#define GCHK(expr)                          \
+    if (rc == BP_OK) {                      \
+        e = (expr);                         \
+        if (e != hipSuccess) {              \
+            set_error("bp_gens_create", e); \
+            rc = BP_EHIP;                   \
+        }                                   \
+    }
+    GCHK(hipMalloc((void**)&d_be, (size_t)np * 64));
+    GCHK(hipMalloc((void**)&g->d_pts, (size_t)np * sizeof(affine)));
+    GCHK(hipMalloc((void**)&g->d_table, g->table_bytes));
+    GCHK(hipMalloc((void**)&d_bases, nidx * sizeof(xyzz)));
+    GCHK(hipMalloc((void**)&d_basesA, nidx * sizeof(affine)));
+    GCHK(hipMalloc((void**)&d_tmp, nent * sizeof(xyzz)));
+    GCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), st));
+    GCHK(hipMemcpyAsync(d_be, host.data(), (size_t)np * 64, hipMemcpyHostToDevice, st));
+    GCHK(launch_ingest_points(d_be, g->d_pts, np, ctx->d_err, st));
+    GCHK(launch_gens_bases(g->d_pts, np, c, W, d_bases, st));
+    GCHK(launch_xyzz_to_affine(d_bases, d_basesA, nidx, st));
+    GCHK(launch_gens_multiples(d_basesA, nidx, NB, d_tmp, st));
+    GCHK(launch_gens_normalize(d_tmp, nent, g->d_table, st));
+    int h_err = 0;
+    GCHK(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    GCHK(hipStreamSynchronize(st));
+#undef GCHK
+    if (rc == BP_OK && h_err) {
+        set_error_msg("generator not on curve");
+        rc = BP_EPOINT;
+    }
+    if (d_be) (void)hipFree(d_be);
+    if (d_bases) (void)hipFree(d_bases);
+    if (d_basesA) (void)hipFree(d_basesA);
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (rc != BP_OK) {
+        bp_gens_destroy(g);
+        return rc;
+    }
+    *out = g;
+    return BP_OK;
+}
+
+void bp_gens_destroy(bp_gens* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->d_pts) (void)hipFree(g->d_pts);
+    if (g->d_table) (void)hipFree(g->d_table);
+    delete g;
+}
+
+size_t bp_gens_table_bytes(const bp_gens* g) { return g ? g->table_bytes : 0; }
+
+void bp_verify_set_lanes(bp_ctx* ctx, int lanes) {
+    if (ctx) ctx->verify_lanes = lanes;
+}
+
+int bp_ctx_sync(bp_ctx* ctx) {
+    if (!ctx) return BP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "sync");
+    return BP_OK;
+}
+
+int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
+                                      const void* d_coms_xy, size_t nproofs, void* d_verdicts) {
+    if (!ctx || !gens || n_bits <= 0 || m <= 0) return BP_EINVAL;
+    if (nproofs == 0) return BP_OK;
+    if (!d_proofs || !d_coms_xy || !d_verdicts) return BP_EINVAL;
+    size_t nm = (size_t)n_bits * m;
+    if (nm != gens->nm || (nm & (nm - 1)) != 0 || gens->device != ctx->device) {
+        set_error_msg("n_bits*m must be a power of two and equal the generators' nm (range_proof.rs:556-558)");
+        return BP_EINVAL;
+    }
+    int k = 0;
+    while (((size_t)1 << k) < nm) k++;
+    if (proof_len != (size_t)292 + 66 * (size_t)k || k > 16) {
+        set_error_msg("proof_len != 292 + 66*log2(nm)");
+        return BP_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t st = ctx->stream;
+    const int NPT = 4 + 2 * k + m, NV = 3 + 2 * k + m;
+    int rc;
+    DevBuf &b_pts = ctx->scratch[0], &b_bad = ctx->scratch[1], &b_dig = ctx->scratch[2], &b_var = ctx->scratch[3], &b_s = ctx->scratch[4];
+    if ((rc = b_pts.reserve(nproofs * NPT * sizeof(affine))) != BP_OK) return rc;
+    if ((rc = b_bad.reserve(nproofs * sizeof(int))) != BP_OK) return rc;
+    if ((rc = b_dig.reserve(nproofs * (size_t)gens->np * gens->W * sizeof(int16_t))) != BP_OK) return rc;
+    if ((rc = b_var.reserve(nproofs * NV * sizeof(fq))) != BP_OK) return rc;
+    if ((rc = b_s.reserve(nproofs * nm * sizeof(fq))) != BP_OK) return rc;
+    HIPCHK(hipMemsetAsync(b_bad.p, 0, nproofs * sizeof(int), st), "memset");
+    HIPCHK(launch_bpv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine*)b_pts.p, (int*)b_bad.p, st),
+           "bpv_decompress");
+    HIPCHK(launch_bpv_scalars((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine*)b_pts.p, gens->d_pts, gens->d_table,
+                              gens->c, gens->W, (int16_t*)b_dig.p, (fq*)b_var.p, (fq*)b_s.p, (int*)b_bad.p, st),
+           "bpv_scalars");
+    int tp = ctx->verify_lanes ? ctx->verify_lanes : 16;
+    if (tp != 16 && tp != 32 && tp != 64) tp = 16;
+    HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, (const affine*)b_pts.p, gens->d_table, gens->c, gens->W, (const int16_t*)b_dig.p,
+                          (const fq*)b_var.p, (const int*)b_bad.p, (uint8_t*)d_verdicts, st),
+           "bpv_msm");
+    return BP_OK;
+}
+
+int bp_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
+                               const uint8_t* coms_xy, size_t nproofs, uint8_t* verdicts) {
+    if (!ctx || !gens || m <= 0) return BP_EINVAL;
+    if (nproofs == 0) return BP_OK;
+    if (!proofs || !coms_xy || !verdicts) return BP_EINVAL;
+    void *d_p, *d_c, *d_v;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+        int rc;
+        if ((rc = ctx->scratch[5].reserve(nproofs * proof_len)) != BP_OK) return rc;
+        if ((rc = ctx->scratch[6].reserve(nproofs * (size_t)m * 64)) != BP_OK) return rc;
+        if ((rc = ctx->scratch[7].reserve(nproofs)) != BP_OK) return rc;
+        d_p = ctx->scratch[5].p;
+        d_c = ctx->scratch[6].p;
+        d_v = ctx->scratch[7].p;
+        HIPCHK(hipMemcpyAsync(d_p, proofs, nproofs * proof_len, hipMemcpyHostToDevice, ctx->stream), "memcpy proofs");
+        HIPCHK(hipMemcpyAsync(d_c, coms_xy, nproofs * (size_t)m * 64, hipMemcpyHostToDevice, ctx->stream), "memcpy coms");
+    }
+    int rc = bp_rangeproof_verify_batch_device(ctx, gens, n_bits, m, d_p, proof_len, d_c, nproofs, d_v);
+    if (rc != BP_OK) return rc;
+    std::vector<uint8_t> tmp(nproofs);
+    HIPCHK(hipMemcpyAsync(tmp.data(), d_v, nproofs, hipMemcpyDeviceToHost, ctx->stream), "memcpy verdicts");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "sync");
+    memcpy(verdicts, tmp.data(), nproofs);
+    return BP_OK;
+}
+
+}  // extern "C"

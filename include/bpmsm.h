@@ -68,6 +68,35 @@ int bp_msm_device(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be
 /* Testing / tuning knob: force the Pippenger window width (0 = automatic). */
 void bp_msm_set_window(bp_ctx* ctx, int c);
 
+/* bp_gens — the shared generators g_vec[nm], h_vec[nm], G, H that the reference passes to every
+ * prove/verify call as slices (range_proof.rs:46-49, 267-270, 539-542; StatementRP,
+ * range_proof_wip.rs:39-45).  Uploaded once and expanded into a fixed-base window table in HBM
+ * (window_bits = 0 picks a width whose table stays <= ~512 MiB); immutable afterwards.
+ * Infinity is not a valid generator (BP_EPOINT). */
+int bp_gens_create(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t nm, const uint8_t G_xy[64], const uint8_t H_xy[64],
+                   int window_bits, bp_gens** out);
+void bp_gens_destroy(bp_gens* gens);
+size_t bp_gens_table_bytes(const bp_gens* gens);
+
+/* bp_rangeproof_verify_batch — `RangeProof::aggregated_verify` (range_proof.rs:537-782) for
+ * nproofs independent proofs that share the generators: every challenge, the scalar vector and the
+ * single 2nm+2k+m+5-term MSM are computed on the GPU; verdicts[i] is one of the BP_VERDICT_* codes.
+ *   proofs  : nproofs * proof_len bytes, canonical encoding (oracle/encoding.py):
+ *             A S T1 T2 (33 B each) | tau_x miu tx (32 B) | L_1..L_k | R_1..R_k (33 B) | a b (32 B),
+ *             proof_len = 292 + 66*k with k = log2(n_bits*m);
+ *   coms_xy : nproofs * m commitments (ped_com), 64 B each.
+ * Returns BP_EINVAL where the reference asserts (:556-562): n_bits*m not a power of two or different
+ * from the gens' nm, proof_len inconsistent. */
+int bp_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
+                               const uint8_t* coms_xy, size_t nproofs, uint8_t* verdicts);
+/* Same with proofs / coms_xy / verdicts already in device memory (DEVICE pointers); asynchronous on
+ * the context's stream until bp_ctx_sync.  This is the call bench.py times. */
+int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
+                                      const void* d_coms_xy, size_t nproofs, void* d_verdicts);
+int bp_ctx_sync(bp_ctx* ctx);
+/* Tuning knob: lanes per proof in the verifier's MSM kernel (16, 32 or 64; 0 = default). */
+void bp_verify_set_lanes(bp_ctx* ctx, int lanes);
+
 #ifdef __cplusplus
 }
 #endif
