@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — verified range proofs/s (secp256k1, n=64, m=1) on N MI355X GPUs.
+
+A "step" is one pass of the hot path over one batch of synthetic proofs: the device-side
+`RangeProof::aggregated_verify` (reference range_proof.rs:537-782) of `--proofs-per-gpu` independent
+n=64, m=1 proofs on every rank (BASELINE.json configs[2], the configuration the metric
+"verified range proofs/sec" is quoted on; weak scaling: per-GPU work fixed, no data-path collective,
+proofs are sharded).  Inputs (proof bytes, commitments) are resident in HBM before the timed region.
+
+Contract (one JSON line on rank 0): metric/value/unit/n_gpus/steps/warmup/ms_per_step/... plus
+  "roofline"     — dominant kernel (k_bpv_msm) against the measured VALU INT32-MAD peak,
+  "cpu_baseline" — the oracle's aggregated_verify ("port") timed on this host, rank 0, N=1 only.
+
+Synthetic data: 256 distinct proofs from tests/golden/bp_c3_batch_n64_m1.json (made by the oracle
+with seeded tapes; the reference cannot run here), tiled to the batch size; every 16th proof of
+the batch is tampered (tx bit flipped) so both verdicts are exercised and checked.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic MAD32 (32x32->64 multiply-accumulates) per n=64 m=1 verification,
+# fixed by the Pippenger model (146-point MSM, c=5) independent of this implementation's choices.
+MAD32_PER_PROOF_MSM = 6.56e6        # the 146-term MSM  (dominant kernel k_bpv_msm)
+MAD32_PER_PROOF_TOTAL = 6.60e6      # + the two fixed-base multiplications y*G, x_u*G
+# Peak: measured with bench_micro/peak_mad32 on MI355X (profiles/r01_peak_mad32.jsonl):
+# v_mad_u64_u32 sustains 31.2e12 lane-results/s at 8 waves/SIMD (SURVEY's assumed quarter-rate
+# figure was 9.83e12; the measured one is the denominator used here).
+PEAK_MAD32_PER_S = 31.2e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--proofs-per-gpu", type=int, default=4096)
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per proof in k_bpv_msm (16/32/64)")
+    ap.add_argument("--window-bits", type=int, default=0, help="fixed-base table window (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=96, help="proofs verified by the CPU baseline")
+    return ap.parse_args()
+
+
+def load_batch():
+    with open(os.path.join(ROOT, "tests", "golden", "bp_c3_batch_n64_m1.json")) as f:
+        b = json.load(f)
+    return b
+
+
+def cpu_baseline(batch, sample):
+    """Oracle aggregated_verify (Python scalar derivation + C term-by-term MSM), one core."""
+    import subprocess
+    from oracle import ec, encoding
+    if not ec.have_c():
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    if not ec.have_c():
+        return None
+    g = bytes.fromhex(batch["g_vec"])
+    h = bytes.fromhex(batch["h_vec"])
+    g_vec = [ec.dec64(g[i:i + 64]) for i in range(0, len(g), 64)]
+    h_vec = [ec.dec64(h[i:i + 64]) for i in range(0, len(h), 64)]
+    G, H = ec.dec64(bytes.fromhex(batch["G"])), ec.dec64(bytes.fromhex(batch["H"]))
+    proofs = bytes.fromhex(batch["proofs"])
+    coms = bytes.fromhex(batch["commitments"])
+    plen = 292 + 66 * 6
+    n_ok = 0
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(min(sample, batch["count"])):
+        p = encoding.decode_bp(proofs[i * plen:(i + 1) * plen])
+        com = [ec.dec64(coms[i * 64:(i + 1) * 64])]
+        n_ok += p.aggregated_verify(g_vec, h_vec, G, H, com, 64) == "Ok"
+        done += 1
+        if time.perf_counter() - t0 > 30:
+            break
+    dt = time.perf_counter() - t0
+    assert n_ok == done
+    return {"value": done / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
+            "sample": "%d n=64 m=1 proofs, oracle aggregated_verify (term-by-term MSM in C, as range_proof.rs:772-774)" % done}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import bulletproofs_amd as bpa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libbpmsm has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    batch = load_batch()
+    P = args.proofs_per_gpu
+    plen = 292 + 66 * 6
+    cnt = batch["count"]
+    proofs = bytearray(bytes.fromhex(batch["proofs"]))
+    coms = bytes.fromhex(batch["commitments"])
+    # tile the 256 distinct proofs to P, rotating by rank so ranks do not hold identical shards
+    order = [(i + 37 * rank) % cnt for i in range(P)]
+    pb = bytearray(P * plen)
+    cb = bytearray(P * 64)
+    want = bytearray(P)
+    for j, i in enumerate(order):
+        pb[j * plen:(j + 1) * plen] = proofs[i * plen:(i + 1) * plen]
+        cb[j * 64:(j + 1) * 64] = coms[i * 64:(i + 1) * 64]
+        if j % 16 == 5:
+            pb[j * plen + 4 * 33 + 64 + 31] ^= 1
+            want[j] = 3
+    d_proofs = torch.frombuffer(pb, dtype=torch.uint8).to(dev)
+    d_coms = torch.frombuffer(cb, dtype=torch.uint8).to(dev)
+    d_verdicts = torch.full((P,), 77, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    ctx = bpa.Context(local_rank)
+    gens = bpa.Gens(ctx, bytes.fromhex(batch["g_vec"]), bytes.fromhex(batch["h_vec"]), bytes.fromhex(batch["G"]),
+                    bytes.fromhex(batch["H"]), args.window_bits)
+    if args.lanes:
+        ctx.set_verify_lanes(args.lanes)
+
+    def step():
+        ctx.rangeproof_verify_batch_device(gens, 64, 1, d_proofs.data_ptr(), plen, d_coms.data_ptr(), P, d_verdicts.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    got = bytes(d_verdicts.cpu().numpy().tobytes())
+    if got != bytes(want):
+        raise SystemExit("verdict mismatch on rank %d" % rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # timed region: exactly K steps, barrier + synchronize on both sides
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel device time of the dominant kernel, HIP events on the library's own stream
+    # (separate pass so event recording does not perturb the timed region)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for _ in range(max(3, min(args.steps, 10))):
+        step()
+        ctx.sync()
+    kms = {}
+    for name, kid in (("bpv_decompress", 0), ("bpv_scalars", 1), ("bpv_msm", 2)):
+        ms, n = ctx.profile_get(kid)
+        kms[name] = ms / max(n, 1)
+    ctx.profile_enable(False)
+
+    if rank == 0:
+        total_proofs = world * P * args.steps
+        value = total_proofs / dt
+        msm_ms = kms["bpv_msm"]
+        achieved = MAD32_PER_PROOF_MSM * P / (msm_ms * 1e-3) if msm_ms > 0 else 0.0
+        out = {
+            "metric": "verified range proofs/sec (secp256k1, n=64) at 1/2/4/8 GPUs; MSM Mpts/s",
+            "value": value,
+            "unit": "proofs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 (256-bit modular integer arithmetic on 8x32-bit limbs)",
+            "data": "synthetic (256 distinct oracle-made proofs tiled to the batch, 1/16 tampered)",
+            "config": {"workload": "batch aggregated_verify of independent n=64 m=1 Bulletproofs range proofs "
+                                   "(BASELINE.json configs[2]), %d proofs per GPU per step, proofs sharded, no collective" % P,
+                       "proofs_per_gpu": P, "msm_terms_per_proof": 147, "table_bytes": gens.table_bytes,
+                       "msm_mpts_per_s": value * 147 / 1e6},
+            "kernel_ms": kms,
+            "roofline": {
+                "bound": "valu_int32_mad",
+                "kernel": "k_bpv_msm",
+                "achieved": achieved / 1e12,
+                "peak": PEAK_MAD32_PER_S / 1e12,
+                "unit": "TMAD32/s",
+                "frac": achieved / PEAK_MAD32_PER_S,
+                "traffic": None,
+                "algorithmic_mad32_per_proof": MAD32_PER_PROOF_MSM,
+                "proofs_per_launch": P,
+                "avg_launch_ms": msm_ms,
+                "whole_job_frac": value / world * MAD32_PER_PROOF_TOTAL / PEAK_MAD32_PER_S,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(batch, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    gens.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

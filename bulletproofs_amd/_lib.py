@@ -24,6 +24,9 @@ EXPORTED_SYMBOLS = [
     "bp_rangeproof_verify_batch_device",
     "bp_ctx_sync",
     "bp_verify_set_lanes",
+    "bp_profile_enable",
+    "bp_profile_reset",
+    "bp_profile_get",
 ]
 
 
@@ -78,6 +81,12 @@ def lib():
     L.bp_ctx_sync.restype = i32
     L.bp_verify_set_lanes.argtypes = [vp, i32]
     L.bp_verify_set_lanes.restype = None
+    L.bp_profile_enable.argtypes = [vp, i32]
+    L.bp_profile_enable.restype = None
+    L.bp_profile_reset.argtypes = [vp]
+    L.bp_profile_reset.restype = None
+    L.bp_profile_get.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
+    L.bp_profile_get.restype = i32
     _lib = L
     return L
 
@@ -133,6 +142,18 @@ class Context:
 
     def sync(self):
         _check(lib().bp_ctx_sync(self._h))
+
+    def profile_enable(self, on=True):
+        lib().bp_profile_enable(self._h, 1 if on else 0)
+
+    def profile_reset(self):
+        lib().bp_profile_reset(self._h)
+
+    def profile_get(self, kernel_id):
+        """(total_ms, launches) accumulated for one kernel id (include/bpmsm.h BP_PROF_*)."""
+        ms, n = ctypes.c_double(), ctypes.c_long()
+        _check(lib().bp_profile_get(self._h, kernel_id, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     def set_verify_lanes(self, lanes):
         lib().bp_verify_set_lanes(self._h, lanes)

@@ -204,6 +204,8 @@ void bp_ctx_destroy(bp_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->release_all();
     if (ctx->d_err) (void)hipFree(ctx->d_err);
+    for (int i = 0; i <= bp_ctx::kMaxProf; i++)
+        if (ctx->prof_ev[i]) (void)hipEventDestroy(ctx->prof_ev[i]);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

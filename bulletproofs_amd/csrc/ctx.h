@@ -35,6 +35,14 @@ struct bp_ctx {
     int* d_err = nullptr;
     int forced_c = 0;
     int verify_lanes = 0;
+    // optional per-kernel timing (bp_profile_*): HIP events on this context's stream
+    bool profiling = false;
+    static const int kMaxProf = 8;
+    hipEvent_t prof_ev[kMaxProf + 1] = {};
+    int prof_n = 0;                 // kernels recorded in the pending call
+    int prof_ids[kMaxProf] = {};
+    double prof_ms[kMaxProf] = {};  // accumulated per kernel id
+    long prof_calls[kMaxProf] = {};
     std::mutex mu;
     bp::DevBuf in_points_be, in_scalars_be, points, digits, partial, wsum, result, initbuf;
     bp::DevBuf scratch[8];

@@ -135,10 +135,54 @@ void bp_verify_set_lanes(bp_ctx* ctx, int lanes) {
     if (ctx) ctx->verify_lanes = lanes;
 }
 
+// fold the event pairs of the pending call into the accumulators (stream must be idle)
+static void prof_collect(bp_ctx* ctx) {
+    for (int i = 0; i < ctx->prof_n; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->prof_ev[i], ctx->prof_ev[i + 1]) == hipSuccess) {
+            ctx->prof_ms[ctx->prof_ids[i]] += ms;
+            ctx->prof_calls[ctx->prof_ids[i]] += 1;
+        }
+    }
+    ctx->prof_n = 0;
+}
+static void prof_mark(bp_ctx* ctx, int slot) {
+    if (ctx->profiling) (void)hipEventRecord(ctx->prof_ev[slot], ctx->stream);
+}
+
 int bp_ctx_sync(bp_ctx* ctx) {
     if (!ctx) return BP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     HIPCHK(hipStreamSynchronize(ctx->stream), "sync");
+    if (ctx->profiling) prof_collect(ctx);
+    return BP_OK;
+}
+
+void bp_profile_enable(bp_ctx* ctx, int on) {
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (on && !ctx->prof_ev[0]) {
+        for (int i = 0; i <= bp_ctx::kMaxProf; i++) (void)hipEventCreate(&ctx->prof_ev[i]);
+    }
+    ctx->profiling = on != 0;
+    ctx->prof_n = 0;
+}
+void bp_profile_reset(bp_ctx* ctx) {
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (int i = 0; i < bp_ctx::kMaxProf; i++) {
+        ctx->prof_ms[i] = 0;
+        ctx->prof_calls[i] = 0;
+    }
+    ctx->prof_n = 0;
+}
+int bp_profile_get(bp_ctx* ctx, int kernel_id, double* total_ms, long* launches) {
+    if (!ctx || kernel_id < 0 || kernel_id >= bp_ctx::kMaxProf) return BP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (total_ms) *total_ms = ctx->prof_ms[kernel_id];
+    if (launches) *launches = ctx->prof_calls[kernel_id];
     return BP_OK;
 }
 
@@ -170,16 +214,30 @@ int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bi
     if ((rc = b_var.reserve(nproofs * NV * sizeof(fq))) != BP_OK) return rc;
     if ((rc = b_s.reserve(nproofs * nm * sizeof(fq))) != BP_OK) return rc;
     HIPCHK(hipMemsetAsync(b_bad.p, 0, nproofs * sizeof(int), st), "memset");
+    if (ctx->profiling && ctx->prof_n) {  // previous call not collected yet: drain it first
+        HIPCHK(hipStreamSynchronize(st), "sync");
+        prof_collect(ctx);
+    }
+    prof_mark(ctx, 0);
     HIPCHK(launch_bpv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine*)b_pts.p, (int*)b_bad.p, st),
            "bpv_decompress");
+    prof_mark(ctx, 1);
     HIPCHK(launch_bpv_scalars((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine*)b_pts.p, gens->d_pts, gens->d_table,
                               gens->c, gens->W, (int16_t*)b_dig.p, (fq*)b_var.p, (fq*)b_s.p, (int*)b_bad.p, st),
            "bpv_scalars");
+    prof_mark(ctx, 2);
     int tp = ctx->verify_lanes ? ctx->verify_lanes : 16;
     if (tp != 16 && tp != 32 && tp != 64) tp = 16;
     HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, (const affine*)b_pts.p, gens->d_table, gens->c, gens->W, (const int16_t*)b_dig.p,
                           (const fq*)b_var.p, (const int*)b_bad.p, (uint8_t*)d_verdicts, st),
            "bpv_msm");
+    prof_mark(ctx, 3);
+    if (ctx->profiling) {
+        ctx->prof_ids[0] = BP_PROF_BPV_DECOMPRESS;
+        ctx->prof_ids[1] = BP_PROF_BPV_SCALARS;
+        ctx->prof_ids[2] = BP_PROF_BPV_MSM;
+        ctx->prof_n = 3;
+    }
     return BP_OK;
 }
 

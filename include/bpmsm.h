@@ -97,6 +97,16 @@ int bp_ctx_sync(bp_ctx* ctx);
 /* Tuning knob: lanes per proof in the verifier's MSM kernel (16, 32 or 64; 0 = default). */
 void bp_verify_set_lanes(bp_ctx* ctx, int lanes);
 
+/* Per-kernel device timing with HIP events on the context's own stream (what bench.py's roofline
+ * block reads; no reference counterpart).  Kernel ids: 0 = bpv_decompress, 1 = bpv_scalars,
+ * 2 = bpv_msm.  Times accumulate from bp_profile_enable(ctx, 1) until bp_profile_reset. */
+#define BP_PROF_BPV_DECOMPRESS 0
+#define BP_PROF_BPV_SCALARS 1
+#define BP_PROF_BPV_MSM 2
+void bp_profile_enable(bp_ctx* ctx, int on);
+void bp_profile_reset(bp_ctx* ctx);
+int bp_profile_get(bp_ctx* ctx, int kernel_id, double* total_ms, long* launches);
+
 #ifdef __cplusplus
 }
 #endif
