@@ -1,0 +1,107 @@
+"""The product's __host__ __device__ arithmetic headers (fp.h, fq.h, ec.h, sha256.h), compiled for
+the CPU into libbpmsm_hosttest.so, against Python big ints / hashlib / the oracle."""
+import ctypes
+import hashlib
+import os
+import random
+import subprocess
+
+import pytest
+
+from oracle import ec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P, Q = ec.P, ec.Q
+
+
+@pytest.fixture(scope="module")
+def L():
+    path = os.path.join(ROOT, "bulletproofs_amd", "libbpmsm_hosttest.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "bulletproofs_amd", "csrc"), "../libbpmsm_hosttest.so"])
+    return ctypes.CDLL(path)
+
+
+def b32(x):
+    return x.to_bytes(32, "big")
+
+
+def call2(f, a, b):
+    o = ctypes.create_string_buffer(32)
+    f(o, b32(a), b32(b))
+    return int.from_bytes(o.raw, "big")
+
+
+def call1(f, a):
+    o = ctypes.create_string_buffer(32)
+    f(o, b32(a))
+    return int.from_bytes(o.raw, "big")
+
+
+def test_fp(L):
+    rng = random.Random(7)
+    edge = [0, 1, 2, P - 1, P - 2, 2**32, 2**32 + 977, 2**255, P - 2**32 - 977, (1 << 224) - 1, P - 977]
+    vals = edge + [rng.randrange(P) for _ in range(120)]
+    for a in vals:
+        for b in rng.sample(vals, 8) + edge:
+            assert call2(L.bpt_fp_mul, a, b) == a * b % P
+            assert call2(L.bpt_fp_add, a, b) == (a + b) % P
+            assert call2(L.bpt_fp_sub, a, b) == (a - b) % P
+        assert call1(L.bpt_fp_sqr, a) == a * a % P
+    for a in vals[:40]:
+        if a:
+            assert call1(L.bpt_fp_inv, a) == pow(a, -1, P)
+        assert call1(L.bpt_fp_sqrt, a) == pow(a, (P + 1) // 4, P)
+
+
+def test_fq(L):
+    rng = random.Random(8)
+    edge = [0, 1, 2, Q - 1, Q - 2, 2**255, 2**128]
+    vals = edge + [rng.randrange(Q) for _ in range(120)]
+    for a in vals:
+        for b in rng.sample(vals, 8) + edge:
+            assert call2(L.bpt_fq_mul, a, b) == a * b % Q
+            assert call2(L.bpt_fq_add, a, b) == (a + b) % Q
+            assert call2(L.bpt_fq_sub, a, b) == (a - b) % Q
+    for a in vals[:30]:
+        if a:
+            assert call1(L.bpt_fq_inv, a) == pow(a, -1, Q)
+    assert call1(L.bpt_fq_reduce, 2**256 - 1) == (2**256 - 1) % Q
+    assert call1(L.bpt_fq_reduce, Q) == 0
+
+
+def test_ec(L, oracle_c):
+    rng = random.Random(9)
+
+    def p2(f, a, b):
+        o = ctypes.create_string_buffer(64)
+        f(o, ec.enc64(a), b if isinstance(b, bytes) else ec.enc64(b))
+        return ec.dec64(o.raw)
+
+    pts = [oracle_c.mul(ec.G, rng.randrange(1, Q)) for _ in range(10)]
+    for a in pts:
+        for b in pts[:4] + [a, ec.neg(a), None]:
+            assert p2(L.bpt_ec_madd, a, b) == oracle_c.add(a, b)
+            assert p2(L.bpt_ec_dbl_add, a, b) == oracle_c.add(oracle_c.add(a, a), b)
+        k = rng.randrange(Q)
+        assert p2(L.bpt_ec_mul, a, b32(k)) == oracle_c.mul(a, k)
+        o = ctypes.create_string_buffer(64)
+        assert L.bpt_ec_decompress(o, ec.compress(a)) == 0 and ec.dec64(o.raw) == a
+        assert L.bpt_ec_on_curve(ec.enc64(a)) == 1
+    assert p2(L.bpt_ec_madd, None, pts[0]) == pts[0]
+    assert p2(L.bpt_ec_mul, pts[0], b32(Q)) is None
+    a = pts[0]
+    assert p2(L.bpt_ec_dbl_add, a, ec.neg(oracle_c.add(a, a))) is None
+    assert p2(L.bpt_ec_dbl_add, a, oracle_c.add(a, a)) == oracle_c.mul(a, 4)
+    o = ctypes.create_string_buffer(64)
+    assert L.bpt_ec_decompress(o, b"\x02" + (5).to_bytes(32, "big")) == -1
+    assert L.bpt_ec_on_curve((1).to_bytes(32, "big") * 2) == 0
+
+
+def test_sha256(L):
+    rng = random.Random(10)
+    for n in [0, 1, 55, 56, 63, 64, 65, 130, 134, 199, 264, 1000]:
+        d = bytes(rng.randrange(256) for _ in range(n))
+        o = ctypes.create_string_buffer(32)
+        L.bpt_sha256(o, d, n)
+        assert o.raw == hashlib.sha256(d).digest(), n

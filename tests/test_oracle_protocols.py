@@ -1,0 +1,139 @@
+"""Oracle regression against the committed golden fixtures + the reference's round-trip tests
+(range_proof.rs:906-1121, inner_product.rs:602-690, weighted_inner_product.rs:863-948,
+range_proof_wip.rs:672-764) re-run through the restatement."""
+import random
+
+import pytest
+
+from oracle import curv, ec, encoding, tape
+from oracle.inner_product import InnerProductArg, inner_product
+from oracle.range_proof import RangeProof
+from oracle.range_proof_wip import RangeProofWIP, StatementRP
+from oracle.weighted_inner_product import WeightedInnerProdArg, weighted_inner_product
+
+from _golden import bp_cases, bpplus_cases
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_bp_golden_reproves_to_same_bytes(oracle_c, idx):
+    case = bp_cases()[idx]
+    n, m = case["n"], case["m"]
+    g_vec, h_vec, G, H = curv.bp_generators(n, m)
+    v = [int(x, 16) for x in case["secrets"]]
+    r = [int(x, 16) for x in case["blindings"]]
+    tp = tape.Tape(bytes.fromhex(case["tape"]))
+    tr = {}
+    proof = RangeProof.prove(g_vec, h_vec, G, H, v, r, n, tp, trace=tr)
+    assert encoding.encode_bp(proof).hex() == case["proof"]
+    assert hex(tr["y"]) == case["challenges"]["y"] and hex(tr["z"]) == case["challenges"]["z"]
+    com = [ec.dec64(bytes.fromhex(c)) for c in case["commitments"]]
+    assert com == [ec.add(ec.mul(G, v[j]), ec.mul(H, r[j])) for j in range(m)]
+    # equivalence triangle: verify == fast_verify == aggregated_verify
+    assert proof.verify(g_vec, h_vec, G, H, com, n) == "Ok"
+    assert proof.fast_verify(g_vec, h_vec, G, H, com, n) == "Ok"
+    assert proof.aggregated_verify(g_vec, h_vec, G, H, com, n) == "Ok"
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_bp_golden_tampered_verdicts(oracle_c, idx):
+    case = bp_cases()[idx]
+    n, m = case["n"], case["m"]
+    g_vec, h_vec, G, H = curv.bp_generators(n, m)
+    for t in case["tampered"]:
+        com = [ec.dec64(bytes.fromhex(c)) for c in t["commitments"]]
+        try:
+            p = encoding.decode_bp(bytes.fromhex(t["proof"]))
+            if p.tx >= ec.Q:
+                raise ValueError
+            got = p.aggregated_verify(g_vec, h_vec, G, H, com, n)
+            assert got == p.fast_verify(g_vec, h_vec, G, H, com, n) == p.verify(g_vec, h_vec, G, H, com, n)
+        except ValueError:
+            got = "Malformed"
+        assert got == t["verdict"], t["name"]
+
+
+def test_bp_out_of_range_secret_rejected(oracle_c):
+    """range_proof.rs:955-1006 (#[should_panic]): v = 2^33 with n = 32 does not verify."""
+    n, m = 8, 2
+    g_vec, h_vec, G, H = curv.bp_generators(n, m)
+    tp = tape.Tape(tape.make_tape_bytes("oor", m + tape.bp_tape_len(n, m)))
+    v = [3, 1 << (n + 1)]
+    r = [tp.random_scalar() for _ in range(m)]
+    com = [ec.add(ec.mul(G, v[j]), ec.mul(H, r[j])) for j in range(m)]
+    proof = RangeProof.prove(g_vec, h_vec, G, H, v, r, n, tp)
+    assert proof.verify(g_vec, h_vec, G, H, com, n) == "RangeProofError"
+    assert proof.aggregated_verify(g_vec, h_vec, G, H, com, n) == "RangeProofError"
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 8])
+def test_ipa_roundtrip(oracle_c, n):
+    """inner_product.rs test_helper / test_helper_fast_verify."""
+    rng = random.Random(n)
+    g_vec = [curv.label_point(i + curv.KZEN_SEED) for i in range(n)]
+    h_vec = [curv.label_point(n + i + curv.KZEN_SEED) for i in range(n)]
+    Gx = curv.label_point(1)
+    a = [rng.randrange(1, ec.Q) for _ in range(n)]
+    b = [rng.randrange(1, ec.Q) for _ in range(n)]
+    c = inner_product(a, b)
+    y = rng.randrange(1, ec.Q)
+    hi_tag = [ec.mul(h_vec[i], pow(pow(y, i, ec.Q), -1, ec.Q)) for i in range(n)]
+    P = ec.msm_naive(hi_tag, b, ec.msm_naive(g_vec, a, ec.mul(Gx, c)))
+    ipp = InnerProductArg.prove(g_vec, hi_tag, Gx, P, a, b)
+    assert len(ipp.L) == n.bit_length() - 1
+    assert ipp.verify(g_vec, hi_tag, Gx, P) == "Ok"
+    assert ipp.fast_verify(g_vec, hi_tag, Gx, P) == "Ok"
+    bad = ec.add(P, ec.G)
+    assert ipp.verify(g_vec, hi_tag, Gx, bad) == "InnerProductError" == ipp.fast_verify(g_vec, hi_tag, Gx, bad)
+
+
+def test_ipa_non_power_of_two_padded(oracle_c):
+    """inner_product.rs:661-690: n = 9 zero-padded to 16 exercises the zero-scalar skip (:74)."""
+    rng = random.Random(9)
+    n, N = 9, 16
+    g_vec = [curv.label_point(i + curv.KZEN_SEED) for i in range(N)]
+    h_vec = [curv.label_point(N + i + curv.KZEN_SEED) for i in range(N)]
+    Gx = curv.label_point(1)
+    a = [rng.randrange(1, ec.Q) for _ in range(n)] + [0] * (N - n)
+    b = [rng.randrange(1, ec.Q) for _ in range(n)] + [0] * (N - n)
+    P = ec.msm_naive(h_vec[:n], b[:n], ec.msm_naive(g_vec[:n], a[:n], ec.mul(Gx, inner_product(a, b))))
+    ipp = InnerProductArg.prove(g_vec, h_vec, Gx, P, a, b)
+    assert ipp.verify(g_vec, h_vec, Gx, P) == "Ok"
+
+
+@pytest.mark.parametrize("n", [1, 2, 8])
+def test_wip_roundtrip(oracle_c, n):
+    """weighted_inner_product.rs test_helper / test_helper_fast_verify."""
+    rng = random.Random(100 + n)
+    g_vec = [curv.label_point(i + curv.KZEN_SEED) for i in range(n)]
+    h_vec = [curv.label_point(n + i + curv.KZEN_SEED) for i in range(n)]
+    g, h = curv.label_point(2), curv.label_point(3)
+    a = [rng.randrange(1, ec.Q) for _ in range(n)]
+    b = [rng.randrange(1, ec.Q) for _ in range(n)]
+    y = curv.sha256().chain(b"Seed string decided by P,V!").result_bigint() % ec.Q
+    c = weighted_inner_product(a, b, y)
+    alpha = rng.randrange(1, ec.Q)
+    P = ec.msm_naive(h_vec, b, ec.msm_naive(g_vec, a, ec.add(ec.mul(g, c), ec.mul(h, alpha))))
+    tp = tape.Tape(tape.make_tape_bytes("wip%d" % n, 2 * (n.bit_length() - 1) + 4))
+    w = WeightedInnerProdArg.prove(g_vec, h_vec, g, h, P, a, b, alpha, y, tp)
+    assert w.verify(g_vec, h_vec, g, h, P, y) == "Ok"
+    assert w.fast_verify(g_vec, h_vec, g, h, P, y) == "Ok"
+    bad = ec.add(P, ec.G)
+    assert w.verify(g_vec, h_vec, g, h, bad, y) == "WeightedInnerProdError" == w.fast_verify(g_vec, h_vec, g, h, bad, y)
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_bpplus_golden(oracle_c, idx):
+    case = bpplus_cases()[idx]
+    n, m = case["n"], case["m"]
+    stmt = StatementRP.generate_bases(curv.KZEN_SEED, m, n)
+    v = [int(x, 16) for x in case["secrets"]]
+    r = [int(x, 16) for x in case["blindings"]]
+    tp = tape.Tape(bytes.fromhex(case["tape"]))
+    proof = RangeProofWIP.prove(stmt, v, r, tp)
+    assert encoding.encode_bpplus(proof).hex() == case["proof"]
+    com = [ec.dec64(bytes.fromhex(c)) for c in case["commitments"]]
+    assert proof.verify(stmt, com) == "Ok" == proof.aggregated_verify(stmt, com)
+    for t in case["tampered"]:
+        p2 = encoding.decode_bpplus(bytes.fromhex(t["proof"]))
+        c2 = [ec.dec64(bytes.fromhex(c)) for c in t["commitments"]]
+        assert p2.aggregated_verify(stmt, c2) == t["verdict"] == p2.verify(stmt, c2)
