@@ -96,16 +96,16 @@ MsmPlan plan_msm(size_t n, int forced_c) {
 
 // out = init + sum scalars[i] * points[i]; d_points (limb form) and d_scalars_be on device.
 // Leaves the result in ctx->d_result (limb form) and ctx->d_result_be; does not synchronise.
-int msm_on_device(bp_ctx* ctx, const affine* d_points, const uint8_t* d_scalars_be, size_t n, const affine* d_init) {
+int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scalars_be, size_t n, const affine_mem* d_init) {
     hipStream_t st = ctx->stream;
     MsmPlan pl = plan_msm(n, ctx->forced_c);
     int rc;
     if ((rc = ctx->digits.reserve((size_t)pl.W * pl.npad * sizeof(int16_t))) != BP_OK) return rc;
     if ((rc = ctx->partial.reserve((size_t)pl.W * pl.S * sizeof(xyzz))) != BP_OK) return rc;
     if ((rc = ctx->wsum.reserve((size_t)pl.W * sizeof(xyzz))) != BP_OK) return rc;
-    if ((rc = ctx->result.reserve(sizeof(affine) + 64)) != BP_OK) return rc;
-    affine* d_res = (affine*)ctx->result.p;
-    uint8_t* d_res_be = (uint8_t*)ctx->result.p + sizeof(affine);
+    if ((rc = ctx->result.reserve(sizeof(affine_mem) + 64)) != BP_OK) return rc;
+    affine_mem* d_res = (affine_mem*)ctx->result.p;
+    uint8_t* d_res_be = (uint8_t*)ctx->result.p + sizeof(affine_mem);
     if (n == 0) {
         // empty sum: result = init (or infinity)
         HIPCHK(hipMemsetAsync(ctx->wsum.p, 0, sizeof(xyzz), st), "memset");
@@ -124,13 +124,13 @@ int msm_on_device(bp_ctx* ctx, const affine* d_points, const uint8_t* d_scalars_
 }
 
 // Upload an optional init point; returns device pointer (or nullptr) in *d_init.
-static int upload_init(bp_ctx* ctx, const uint8_t* init_xy, const affine** d_init) {
+static int upload_init(bp_ctx* ctx, const uint8_t* init_xy, const affine_mem** d_init) {
     *d_init = nullptr;
     if (!init_xy) return BP_OK;
     int rc;
-    if ((rc = ctx->initbuf.reserve(64 + sizeof(affine))) != BP_OK) return rc;
+    if ((rc = ctx->initbuf.reserve(64 + sizeof(affine_mem))) != BP_OK) return rc;
     HIPCHK(hipMemcpyAsync(ctx->initbuf.p, init_xy, 64, hipMemcpyHostToDevice, ctx->stream), "memcpy init");
-    affine* d = (affine*)((uint8_t*)ctx->initbuf.p + 64);
+    affine_mem* d = (affine_mem*)((uint8_t*)ctx->initbuf.p + 64);
     HIPCHK(launch_ingest_points((const uint8_t*)ctx->initbuf.p, d, 1, ctx->d_err, ctx->stream), "ingest init");
     *d_init = d;
     return BP_OK;
@@ -139,7 +139,7 @@ static int upload_init(bp_ctx* ctx, const uint8_t* init_xy, const affine** d_ini
 static int fetch_result(bp_ctx* ctx, uint8_t out_xy[64]) {
     int h_err = 0;
     uint8_t tmp[64];
-    HIPCHK(hipMemcpyAsync(tmp, (uint8_t*)ctx->result.p + sizeof(affine), 64, hipMemcpyDeviceToHost, ctx->stream), "memcpy out");
+    HIPCHK(hipMemcpyAsync(tmp, (uint8_t*)ctx->result.p + sizeof(affine_mem), 64, hipMemcpyDeviceToHost, ctx->stream), "memcpy out");
     HIPCHK(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), "memcpy err");
     HIPCHK(hipStreamSynchronize(ctx->stream), "sync");
     if (h_err) {
@@ -220,11 +220,11 @@ int bp_msm_device(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream), "memset err");
     int rc;
-    if ((rc = ctx->points.reserve((n ? n : 1) * sizeof(affine))) != BP_OK) return rc;
-    HIPCHK(launch_ingest_points((const uint8_t*)d_points_xy, (affine*)ctx->points.p, n, ctx->d_err, ctx->stream), "ingest");
-    const affine* d_init;
+    if ((rc = ctx->points.reserve((n ? n : 1) * sizeof(affine_mem))) != BP_OK) return rc;
+    HIPCHK(launch_ingest_points((const uint8_t*)d_points_xy, (affine_mem*)ctx->points.p, n, ctx->d_err, ctx->stream), "ingest");
+    const affine_mem* d_init;
     if ((rc = upload_init(ctx, init_xy, &d_init)) != BP_OK) return rc;
-    if ((rc = msm_on_device(ctx, (const affine*)ctx->points.p, (const uint8_t*)d_scalars_be, n, d_init)) != BP_OK) return rc;
+    if ((rc = msm_on_device(ctx, (const affine_mem*)ctx->points.p, (const uint8_t*)d_scalars_be, n, d_init)) != BP_OK) return rc;
     return fetch_result(ctx, out_xy);
 }
 

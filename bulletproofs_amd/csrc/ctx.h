@@ -46,6 +46,7 @@ struct bp_ctx {
     std::mutex mu;
     bp::DevBuf in_points_be, in_scalars_be, points, digits, partial, wsum, result, initbuf;
     bp::DevBuf scratch[8];
+    bp::DevBuf vartab;
     void release_all() {
         in_points_be.release();
         in_scalars_be.release();
@@ -56,9 +57,10 @@ struct bp_ctx {
         result.release();
         initbuf.release();
         for (auto& s : scratch) s.release();
+        vartab.release();
     }
 };
 
 namespace bp {
-int msm_on_device(bp_ctx* ctx, const affine* d_points, const uint8_t* d_scalars_be, size_t n, const affine* d_init);
+int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scalars_be, size_t n, const affine_mem* d_init);
 }

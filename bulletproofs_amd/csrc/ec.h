@@ -2,24 +2,38 @@
 //
 // Replaces `Point<Secp256k1>` `+`, `-`, `*` of curv-kzen (call sites: every fold idiom of SURVEY.md
 // §2.2, e.g. /root/reference/src/proofs/range_proof.rs:770-774).  XYZZ is chosen because the MSM
-// hot loop is affine-into-accumulator additions: 8M + 2S (mixed) against 11M + 5S... for Jacobian
-// full adds, with no inversion until the very end.  Infinity is ZZ == 0.
+// hot loop is affine-into-accumulator additions: 8M + 2S (mixed) with no inversion until the very
+// end.  The reference's generator recipe makes h_vec[i] == g_vec[i+n] (range_proof.rs:837-841), so
+// equal and opposite operands DO occur inside one accumulator: every add handles P+P and P+(-P).
 //
-// The reference's generator recipe makes h_vec[i] == g_vec[i+n] (range_proof.rs:837-841), so equal
-// and opposite operands DO occur inside one accumulator: every add handles P+P and P+(-P).
+// Types: `affine` / `xyzz` are the in-register compute forms (fp = 9x29-bit limbs);
+// `affine_mem` is the 64-byte canonical storage form used for every point array in HBM (tables,
+// generators, proof points): one cache line per gather.
+// Infinity markers: affine x = y = 0 (raw zero limbs; not a curve point since b = 7), xyzz ZZ = 0
+// (raw).  They are only ever created by affine_inf()/xyzz_inf() or zeroed memory, never by
+// arithmetic, so the tests are raw limb tests (no canonicalisation needed).
 #pragma once
 #include "fp.h"
 
 namespace bp {
 
-struct affine {  // 64 bytes; infinity is encoded as x = y = 0 (not a curve point since b = 7)
+struct affine {
     fp x, y;
 };
 struct xyzz {
     fp X, Y, ZZ, ZZZ;
 };
+struct affine_mem {  // 64 bytes: x words then y words, canonical; all-zero = infinity
+    fp_words x, y;
+};
 
-BP_HD bool affine_is_inf(const affine& p) { return fp_is_zero(p.x) && fp_is_zero(p.y); }
+BP_HD bool fp_raw_is_zero(const fp& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= a.v[i];
+    return o == 0;
+}
+BP_HD bool affine_is_inf(const affine& p) { return fp_raw_is_zero(p.x) && fp_raw_is_zero(p.y); }
 BP_HD affine affine_inf() {
     affine r;
     r.x = fp_zero();
@@ -27,14 +41,38 @@ BP_HD affine affine_inf() {
     return r;
 }
 BP_HD affine affine_neg(const affine& p) {
+    if (affine_is_inf(p)) return p;
     affine r;
     r.x = p.x;
     r.y = fp_neg(p.y);
     return r;
 }
-BP_HD bool affine_eq(const affine& a, const affine& b) { return fp_eq(a.x, b.x) && fp_eq(a.y, b.y); }
+BP_HD bool affine_eq(const affine& a, const affine& b) {
+    bool ia = affine_is_inf(a), ib = affine_is_inf(b);
+    if (ia || ib) return ia && ib;
+    return fp_eq(a.x, b.x) && fp_eq(a.y, b.y);
+}
 
-BP_HD bool xyzz_is_inf(const xyzz& p) { return fp_is_zero(p.ZZ); }
+BP_HD affine affine_load(const affine_mem& m) {
+    affine r;
+    r.x = fp_from_words(m.x);
+    r.y = fp_from_words(m.y);
+    return r;
+}
+BP_HD affine_mem affine_store(const affine& p) {
+    affine_mem m;
+    if (affine_is_inf(p)) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) m.x.w[i] = m.y.w[i] = 0;
+        return m;
+    }
+    m.x = fp_to_words(p.x);
+    m.y = fp_to_words(p.y);
+    return m;
+}
+BP_HD bool affine_mem_is_inf(const affine_mem& m) { return fp_words_is_zero(m.x) && fp_words_is_zero(m.y); }
+
+BP_HD bool xyzz_is_inf(const xyzz& p) { return fp_raw_is_zero(p.ZZ); }
 BP_HD xyzz xyzz_inf() {
     xyzz r;
     r.X = fp_zero();
@@ -58,9 +96,9 @@ BP_HD xyzz xyzz_neg(const xyzz& p) {
     return r;
 }
 
-// dbl-2008-s-1 with a = 0: 6M + 3S.
+// dbl-2008-s-1 with a = 0: 6M + 3S.  (secp256k1 has prime order: no point has Y = 0.)
 BP_HD xyzz xyzz_dbl(const xyzz& p) {
-    if (xyzz_is_inf(p) || fp_is_zero(p.Y)) return xyzz_inf();
+    if (xyzz_is_inf(p)) return xyzz_inf();
     xyzz r;
     fp U = fp_dbl(p.Y);
     fp V = fp_sqr(U);
@@ -75,9 +113,9 @@ BP_HD xyzz xyzz_dbl(const xyzz& p) {
     return r;
 }
 
-// doubling of an affine point (mdbl-2008-s-1): 2M + 3S... (ZZ = ZZZ = 1).
+// doubling of an affine point (mdbl-2008-s-1; ZZ = ZZZ = 1).
 BP_HD xyzz xyzz_dbl_affine(const affine& p) {
-    if (affine_is_inf(p) || fp_is_zero(p.y)) return xyzz_inf();
+    if (affine_is_inf(p)) return xyzz_inf();
     xyzz r;
     fp U = fp_dbl(p.y);
     fp V = fp_sqr(U);
@@ -92,7 +130,7 @@ BP_HD xyzz xyzz_dbl_affine(const affine& p) {
     return r;
 }
 
-// acc += p (p affine, not infinity-checked by callers that skip zero digits): madd-2008-s, 8M + 2S.
+// acc += p (p affine): madd-2008-s, 8M + 2S.
 BP_HD void xyzz_madd(xyzz& acc, const affine& p) {
     if (affine_is_inf(p)) return;
     if (xyzz_is_inf(acc)) {
@@ -152,10 +190,9 @@ BP_HD void xyzz_add(xyzz& acc, const xyzz& q) {
     acc.ZZZ = fp_mul(fp_mul(acc.ZZZ, q.ZZZ), PPP);
 }
 
-// Canonical affine form (one field inversion): the group element the reference would hold.
+// Affine form (one field inversion).  1/ZZZ = Z^-3, ZZ/ZZZ = Z^-1.
 BP_HD affine xyzz_to_affine(const xyzz& p) {
     if (xyzz_is_inf(p)) return affine_inf();
-    // 1/ZZZ; then 1/ZZ = ZZ^2 / ZZZ^2 ... use: zi3 = 1/ZZZ, zi2 = (ZZ * zi3)^2 since ZZ^3 = ZZZ^2 => ZZ/ZZZ = 1/Z
     fp zi3 = fp_inv(p.ZZZ);
     fp zi = fp_mul(p.ZZ, zi3);
     fp zi2 = fp_sqr(zi);
@@ -177,13 +214,14 @@ BP_HD bool affine_on_curve(const affine& p) {
 // 33-byte SEC1 compressed -> affine (curv `Point::from_bytes`); false if not a curve point.
 BP_HD bool affine_decompress(affine& out, const uint8_t* b33) {
     if (b33[0] != 2 && b33[0] != 3) return false;
-    fp x = fp_from_be(b33 + 1);
-    if (!fp_is_canonical(x)) return false;
+    fp_words xw = fp_words_from_be(b33 + 1);
+    if (!fp_words_is_canonical(xw)) return false;
+    fp x = fp_from_words(xw);
     fp rhs = fp_mul(fp_sqr(x), x);
     fp seven = fp_zero();
     seven.v[0] = 7;
     rhs = fp_add(rhs, seven);
-    fp y = fp_sqrt_candidate(rhs);
+    fp y = fp_canon(fp_sqrt_candidate(rhs));
     if (!fp_eq(fp_sqr(y), rhs)) return false;
     if ((y.v[0] & 1u) != (uint32_t)(b33[0] & 1u)) y = fp_neg(y);
     out.x = x;
@@ -191,16 +229,30 @@ BP_HD bool affine_decompress(affine& out, const uint8_t* b33) {
     return true;
 }
 
+// memory form with validation: canonical coordinates and on the curve (infinity allowed only if asked)
+BP_HD bool affine_mem_valid(const affine_mem& m, bool allow_inf) {
+    if (affine_mem_is_inf(m)) return allow_inf;
+    if (!fp_words_is_canonical(m.x) || !fp_words_is_canonical(m.y)) return false;
+    return affine_on_curve(affine_load(m));
+}
+
 // boundary encoding: x||y big-endian, 64 zero bytes = infinity (include/bpmsm.h)
 BP_HD void affine_to_be64(uint8_t* b, const affine& p) {
-    fp_to_be(b, p.x);
-    fp_to_be(b + 32, p.y);
+    affine_mem m = affine_store(p);
+    fp_words_to_be(b, m.x);
+    fp_words_to_be(b + 32, m.y);
 }
 BP_HD affine affine_from_be64(const uint8_t* b) {
     affine r;
     r.x = fp_from_be(b);
     r.y = fp_from_be(b + 32);
     return r;
+}
+BP_HD affine_mem affine_mem_from_be64(const uint8_t* b) {
+    affine_mem m;
+    m.x = fp_words_from_be(b);
+    m.y = fp_words_from_be(b + 32);
+    return m;
 }
 
 }  // namespace bp

@@ -1,15 +1,24 @@
-// secp256k1 base field F_p, p = 2^256 - 2^32 - 977, on 8 x 32-bit limbs (little-endian limb order).
+// secp256k1 base field F_p, p = 2^256 - 2^32 - 977, for CDNA4's 32-bit VALU.
 //
 // Replaces the field arithmetic libsecp256k1 performs behind curv-kzen's `Point<Secp256k1>` operators
 // (reference call sites: every `&Point * &Scalar` / `Point + Point`, e.g.
-// /root/reference/src/proofs/range_proof.rs:773-774).  Written for CDNA4's 32-bit VALU: products are
-// `v_mad_u64_u32` chains (acc64 += a32*b32), reduction uses the pseudo-Mersenne fold
-// 2^256 = 2^32 + 977 (mod p) instead of a Montgomery pass: 9 extra multiplies instead of 72, and the
-// values stay in the plain (non-Montgomery) domain so they are bit-identical to the canonical
-// coordinates the reference serialises.  All results are fully reduced to [0, p).
+// /root/reference/src/proofs/range_proof.rs:773-774).
 //
-// Every function is __host__ __device__ so the same code is unit-tested on the CPU (tests/) and
-// used by the host-side protocol layer.
+// Representation: 9 limbs of 29 bits ("reduced radix", value = sum v[i] * 2^(29 i)).  Measured on
+// MI355X (profiles/r01_peak_mad32.jsonl): v_mad_u64_u32 issues in ~5 cycles per wave, but every
+// carry instruction around it (v_addc_co_u32, 64-bit add) costs ~4, so a saturated 8x32 schoolbook
+// spends more time on carries than on multiplies.  With 29-bit limbs a whole product column
+// (9 products < 2^60) accumulates in one 64-bit register pair with NO carry handling: the product is
+// a pure `v_mad_u64_u32 acc, a, b, acc` chain (81 MADs), carries are resolved once per column with a
+// shift and a mask.  Reduction uses the pseudo-Mersenne fold 2^256 = 2^32 + 977 (mod p): values stay
+// in the plain domain, bit-identical to the canonical coordinates the reference serialises.
+//
+// Invariant of every fp value at rest ("weakly normalised"):
+//     v[0..7] <= 2^29 + 2^12,   v[8] <= 2^24 + 2^12      (value < 2^256 + 2^45, not nec. < p)
+// Canonical form (unique, < p) is produced only where bytes leave (fp_to_words) or for equality tests.
+//
+// Storage format in HBM / at the boundary is the canonical 8 x 32-bit words (`fp_words`, 32 bytes).
+// Every function is __host__ __device__: the same code is unit-tested on the CPU (tests/).
 #pragma once
 #include <stdint.h>
 
@@ -17,8 +26,8 @@
 #include <hip/hip_runtime.h>
 #define BP_HD __host__ __device__ __forceinline__
 #define BP_HD_NOINLINE inline __host__ __device__ __noinline__
-// fp_mul / fp_sqr are ~300 VALU instructions each; a point addition inlines 10-14 of them.  Calling
-// them as real functions keeps kernels inside the instruction cache (override to measure).
+// fp_mul / fp_sqr are a few hundred VALU instructions each; a point addition uses 10-14 of them.
+// Calling them as real functions keeps kernels inside the instruction cache (override to measure).
 #ifndef BP_FP_MUL_INLINE
 #define BP_HD_MUL inline __host__ __device__ __noinline__
 #else
@@ -33,16 +42,19 @@
 namespace bp {
 
 struct fp {
-    uint32_t v[8];
+    uint32_t v[9];
+};
+struct fp_words {  // canonical value < p as 8 little-endian 32-bit words (memory / wire format)
+    uint32_t w[8];
 };
 
-// 2^256 - p = 2^32 + 977
-#define BP_P_C0 977u
+#define BP_M29 0x1FFFFFFFu
+#define BP_P_C0 977u  // 2^256 - p = 2^32 + 977 = 977 + 8 * 2^29
 
 BP_HD fp fp_zero() {
     fp r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = 0;
+    for (int i = 0; i < 9; i++) r.v[i] = 0;
     return r;
 }
 BP_HD fp fp_one() {
@@ -50,207 +62,142 @@ BP_HD fp fp_one() {
     r.v[0] = 1;
     return r;
 }
+
+// Carry-propagate limbs (< 2^32 each) and fold bits >= 256 back in: restores the invariant.
+BP_HD void fp_normalize(uint32_t v[9]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        v[i + 1] += v[i] >> 29;
+        v[i] &= BP_M29;
+    }
+    uint32_t e = v[8] >> 24;
+    v[8] &= 0x00FFFFFFu;
+    v[0] += e * BP_P_C0;
+    v[1] += e << 3;
+    v[1] += v[0] >> 29;
+    v[0] &= BP_M29;
+}
+
+// Unique representative in [0, p).
+BP_HD fp fp_canon(const fp& a) {
+    fp r = a;
+    fp_normalize(r.v);
+    // full carry chain (no fold): limbs < 2^29, v[8] <= 2^24, value < 2p
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r.v[i + 1] += r.v[i] >> 29;
+        r.v[i] &= BP_M29;
+    }
+    // s = r + (2^32 + 977); if bit 256 of s is set then r >= p and r - p = s - 2^256
+    uint32_t s[9];
+    s[0] = r.v[0] + BP_P_C0;
+    s[1] = r.v[1] + 8u + (s[0] >> 29);
+    s[0] &= BP_M29;
+#pragma unroll
+    for (int i = 2; i < 9; i++) {
+        s[i] = r.v[i] + (s[i - 1] >> 29);
+        s[i - 1] &= BP_M29;
+    }
+    if (s[8] >> 24) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = s[i];
+        r.v[8] = s[8] & 0x00FFFFFFu;
+    }
+    return r;
+}
+
 BP_HD bool fp_is_zero(const fp& a) {
+    fp c = fp_canon(a);
     uint32_t o = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) o |= a.v[i];
+    for (int i = 0; i < 9; i++) o |= c.v[i];
     return o == 0;
-}
-BP_HD bool fp_eq(const fp& a, const fp& b) {
-    uint32_t o = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
-    return o == 0;
-}
-
-// r + (2^32 + 977) over 8 limbs; returns the carry out of limb 7.
-BP_HD uint32_t fp_add_c(uint32_t s[8], const uint32_t r[8]) {
-    uint64_t c = (uint64_t)r[0] + BP_P_C0;
-    s[0] = (uint32_t)c;
-    c >>= 32;
-    c += (uint64_t)r[1] + 1u;
-    s[1] = (uint32_t)c;
-    c >>= 32;
-#pragma unroll
-    for (int i = 2; i < 8; i++) {
-        c += r[i];
-        s[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    return (uint32_t)c;
-}
-
-// Final conditional subtraction of p given value = carry*2^256 + r, value < 2p.
-BP_HD void fp_final_reduce(uint32_t r[8], uint32_t carry) {
-    uint32_t s[8];
-    uint32_t c2 = fp_add_c(s, r);
-    if (carry | c2) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) r[i] = s[i];
-    }
 }
 
 BP_HD fp fp_add(const fp& a, const fp& b) {
     fp r;
-    uint64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)a.v[i] + b.v[i];
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    fp_final_reduce(r.v, (uint32_t)c);
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
+    fp_normalize(r.v);
     return r;
 }
 
+// a - b = a + K - b with K = 4p written with every limb >= 2^30 - 2 (>= any limb of b).
 BP_HD fp fp_sub(const fp& a, const fp& b) {
+    const uint32_t K[9] = {0x5ffff0bcu, 0x5fffffddu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x03fffffdu};
     fp r;
-    int64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (int64_t)a.v[i] - (int64_t)b.v[i];
-        r.v[i] = (uint32_t)c;
-        c >>= 32;  // arithmetic shift: 0 or -1
-    }
-    if (c) {
-        // a - b + 2^256 - (2^32 + 977) = a - b + p
-        int64_t d = (int64_t)r.v[0] - (int64_t)BP_P_C0;
-        r.v[0] = (uint32_t)d;
-        d >>= 32;
-        d += (int64_t)r.v[1] - 1;
-        r.v[1] = (uint32_t)d;
-        d >>= 32;
-#pragma unroll
-        for (int i = 2; i < 8; i++) {
-            d += (int64_t)r.v[i];
-            r.v[i] = (uint32_t)d;
-            d >>= 32;
-        }
-    }
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + K[i] - b.v[i];
+    fp_normalize(r.v);
     return r;
 }
-
 BP_HD fp fp_neg(const fp& a) { return fp_sub(fp_zero(), a); }
 BP_HD fp fp_dbl(const fp& a) { return fp_add(a, a); }
+BP_HD bool fp_eq(const fp& a, const fp& b) { return fp_is_zero(fp_sub(a, b)); }
 
-// Reduce a 512-bit product t[0..15] modulo p.
-BP_HD fp fp_reduce512(const uint32_t t[16]) {
-    // u = hi * 977 (9 limbs)
-    uint32_t u[9];
-    uint64_t c = 0;
+// Reduce 18 product limbs r[0..17] (29 bits each, r[17] small) modulo p.
+// 2^261 = 2^5 (2^32 + 977) = 256 * 2^29 + 31264  (mod p).
+BP_HD fp fp_fold18(const uint32_t r[18]) {
+    fp o;
+    uint64_t c = (uint64_t)r[9] * 31264u + r[0];
+    o.v[0] = (uint32_t)c & BP_M29;
+    c >>= 29;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        c += (uint64_t)t[8 + j] * BP_P_C0;
-        u[j] = (uint32_t)c;
-        c >>= 32;
+    for (int k = 1; k < 9; k++) {
+        c += (uint64_t)r[9 + k] * 31264u + r[k];
+        c += (uint64_t)r[8 + k] << 8;
+        o.v[k] = (uint32_t)c & BP_M29;
+        c >>= 29;
     }
-    u[8] = (uint32_t)c;
-    // r = lo + u + (hi << 32); limb 8 collects the overflow T (< 2^34)
-    fp r;
-    c = (uint64_t)t[0] + u[0];
-    r.v[0] = (uint32_t)c;
-    c >>= 32;
-#pragma unroll
-    for (int k = 1; k < 8; k++) {
-        c += (uint64_t)t[k] + u[k];
-        c += t[8 + k - 1];
-        r.v[k] = (uint32_t)c;
-        c >>= 32;
-    }
-    uint64_t T = c + (uint64_t)u[8] + t[15];
-    // fold T * (2^32 + 977) back in
-    uint64_t m = T * BP_P_C0;  // < 2^44
-    c = (uint64_t)r.v[0] + (uint32_t)m;
-    r.v[0] = (uint32_t)c;
-    c >>= 32;
-    c += (uint64_t)r.v[1] + (m >> 32) + (uint32_t)T;
-    r.v[1] = (uint32_t)c;
-    c >>= 32;
-    c += (uint64_t)r.v[2] + (T >> 32);
-    r.v[2] = (uint32_t)c;
-    c >>= 32;
-#pragma unroll
-    for (int k = 3; k < 8; k++) {
-        c += r.v[k];
-        r.v[k] = (uint32_t)c;
-        c >>= 32;
-    }
-    fp_final_reduce(r.v, (uint32_t)c);
-    return r;
+    c += (uint64_t)r[17] << 8;  // weight 2^261
+    // E = everything at or above 2^256
+    uint64_t E = (uint64_t)(o.v[8] >> 24) + (c << 5);
+    o.v[8] &= 0x00FFFFFFu;
+    c = (uint64_t)o.v[0] + E * BP_P_C0;
+    o.v[0] = (uint32_t)c & BP_M29;
+    c >>= 29;
+    c += (uint64_t)o.v[1] + (E << 3);
+    o.v[1] = (uint32_t)c & BP_M29;
+    c >>= 29;
+    c += o.v[2];
+    o.v[2] = (uint32_t)c & BP_M29;
+    c >>= 29;
+    o.v[3] += (uint32_t)c;
+    return o;
 }
 
-// 8x8 schoolbook product, operand scanning: 64 multiply-accumulates (the MAD32 unit of SURVEY.md §8d).
-BP_HD void fp_mul_wide(uint32_t t[16], const fp& a, const fp& b) {
-    uint64_t c = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        c += (uint64_t)a.v[0] * b.v[j];
-        t[j] = (uint32_t)c;
-        c >>= 32;
-    }
-    t[8] = (uint32_t)c;
-#pragma unroll
-    for (int i = 1; i < 8; i++) {
-        c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            c += (uint64_t)a.v[i] * b.v[j] + t[i + j];
-            t[i + j] = (uint32_t)c;
-            c >>= 32;
-        }
-        t[i + 8] = (uint32_t)c;
-    }
-}
-
+// 9x9 product scanning: each column is one 64-bit accumulator fed by v_mad_u64_u32; 81 MADs.
 BP_HD_MUL fp fp_mul(fp a, fp b) {
-    uint32_t t[16];
-    fp_mul_wide(t, a, b);
-    return fp_reduce512(t);
+    uint32_t r[18];
+    uint64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++) c += (uint64_t)a.v[i] * b.v[k - i];
+        r[k] = (uint32_t)c & BP_M29;
+        c >>= 29;
+    }
+    r[17] = (uint32_t)c;
+    return fp_fold18(r);
 }
 
-// Squaring: 36 multiplies (off-diagonal products computed once and doubled).
+// Squaring: 45 MADs (off-diagonal terms use a doubled operand).
 BP_HD_MUL fp fp_sqr(fp a) {
-    uint32_t t[16];
-    // off-diagonal: sum_{i<j} a_i a_j 2^{32(i+j)}
+    uint32_t d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
+    uint32_t r[18];
     uint64_t c = 0;
-    t[0] = 0;
 #pragma unroll
-    for (int j = 1; j < 8; j++) {
-        c += (uint64_t)a.v[0] * a.v[j];
-        t[j] = (uint32_t)c;
-        c >>= 32;
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = (k > 8 ? k - 8 : 0); 2 * i < k; i++) c += (uint64_t)d[i] * a.v[k - i];
+        if ((k & 1) == 0) c += (uint64_t)a.v[k / 2] * a.v[k / 2];
+        r[k] = (uint32_t)c & BP_M29;
+        c >>= 29;
     }
-    t[8] = (uint32_t)c;
-#pragma unroll
-    for (int i = 1; i < 7; i++) {
-        c = 0;
-#pragma unroll
-        for (int j = i + 1; j < 8; j++) {
-            c += (uint64_t)a.v[i] * a.v[j] + t[i + j];
-            t[i + j] = (uint32_t)c;
-            c >>= 32;
-        }
-        t[i + 8] = (uint32_t)c;
-    }
-    t[15] = 0;
-    // double and add the diagonal
-    uint32_t top = 0;
-#pragma unroll
-    for (int k = 15; k > 0; k--) t[k] = (t[k] << 1) | (t[k - 1] >> 31);
-    t[0] <<= 1;
-    (void)top;
-    c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t d = (uint64_t)a.v[i] * a.v[i];
-        c += (uint64_t)t[2 * i] + (uint32_t)d;
-        t[2 * i] = (uint32_t)c;
-        c >>= 32;
-        c += (uint64_t)t[2 * i + 1] + (d >> 32);
-        t[2 * i + 1] = (uint32_t)c;
-        c >>= 32;
-    }
-    return fp_reduce512(t);
+    r[17] = (uint32_t)c;
+    return fp_fold18(r);
 }
 
 BP_HD fp fp_sqr_n(fp a, int n) {
@@ -297,30 +244,79 @@ BP_HD_NOINLINE fp fp_sqrt_candidate(fp a) {
     return t;
 }
 
-// 32 big-endian bytes <-> limbs.  from_be does not reduce; callers check fp_is_canonical.
-BP_HD fp fp_from_be(const uint8_t* b) {
+// ---- conversions between the compute form and the canonical 8x32 storage form -------------------
+BP_HD fp fp_from_words(const fp_words& s) {
+    const uint32_t* w = s.w;
     fp r;
+    r.v[0] = w[0] & BP_M29;
+    r.v[1] = ((w[0] >> 29) | (w[1] << 3)) & BP_M29;
+    r.v[2] = ((w[1] >> 26) | (w[2] << 6)) & BP_M29;
+    r.v[3] = ((w[2] >> 23) | (w[3] << 9)) & BP_M29;
+    r.v[4] = ((w[3] >> 20) | (w[4] << 12)) & BP_M29;
+    r.v[5] = ((w[4] >> 17) | (w[5] << 15)) & BP_M29;
+    r.v[6] = ((w[5] >> 14) | (w[6] << 18)) & BP_M29;
+    r.v[7] = ((w[6] >> 11) | (w[7] << 21)) & BP_M29;
+    r.v[8] = w[7] >> 8;
+    return r;
+}
+// canonicalises first: the words are the unique value in [0, p)
+BP_HD fp_words fp_to_words(const fp& a) {
+    fp c = fp_canon(a);
+    const uint32_t* v = c.v;
+    fp_words s;
+    s.w[0] = v[0] | (v[1] << 29);
+    s.w[1] = (v[1] >> 3) | (v[2] << 26);
+    s.w[2] = (v[2] >> 6) | (v[3] << 23);
+    s.w[3] = (v[3] >> 9) | (v[4] << 20);
+    s.w[4] = (v[4] >> 12) | (v[5] << 17);
+    s.w[5] = (v[5] >> 15) | (v[6] << 14);
+    s.w[6] = (v[6] >> 18) | (v[7] << 11);
+    s.w[7] = (v[7] >> 21) | (v[8] << 8);
+    return s;
+}
+// words < p ?  (for validating untrusted input)
+BP_HD bool fp_words_is_canonical(const fp_words& s) {
+    // s + (2^32 + 977) must not carry out of 256 bits
+    uint64_t c = (uint64_t)s.w[0] + BP_P_C0;
+    c >>= 32;
+    c += (uint64_t)s.w[1] + 1u;
+    c >>= 32;
+#pragma unroll
+    for (int i = 2; i < 8; i++) {
+        c += s.w[i];
+        c >>= 32;
+    }
+    return c == 0;
+}
+BP_HD bool fp_words_is_zero(const fp_words& s) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= s.w[i];
+    return o == 0;
+}
+
+// 32 big-endian bytes <-> words / fp.  from_be does not range-check (fp_words_is_canonical does).
+BP_HD fp_words fp_words_from_be(const uint8_t* b) {
+    fp_words r;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint8_t* q = b + 4 * (7 - i);
-        r.v[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+        r.w[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
     }
     return r;
 }
-BP_HD void fp_to_be(uint8_t* b, const fp& a) {
+BP_HD void fp_words_to_be(uint8_t* b, const fp_words& a) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         uint8_t* q = b + 4 * (7 - i);
-        q[0] = (uint8_t)(a.v[i] >> 24);
-        q[1] = (uint8_t)(a.v[i] >> 16);
-        q[2] = (uint8_t)(a.v[i] >> 8);
-        q[3] = (uint8_t)(a.v[i]);
+        q[0] = (uint8_t)(a.w[i] >> 24);
+        q[1] = (uint8_t)(a.w[i] >> 16);
+        q[2] = (uint8_t)(a.w[i] >> 8);
+        q[3] = (uint8_t)(a.w[i]);
     }
 }
-// value < p ?
-BP_HD bool fp_is_canonical(const fp& a) {
-    uint32_t s[8];
-    return fp_add_c(s, a.v) == 0;
-}
+BP_HD fp fp_from_be(const uint8_t* b) { return fp_from_words(fp_words_from_be(b)); }
+BP_HD void fp_to_be(uint8_t* b, const fp& a) { fp_words_to_be(b, fp_to_words(a)); }
+BP_HD bool fp_be_is_canonical(const uint8_t* b) { return fp_words_is_canonical(fp_words_from_be(b)); }
 
 }  // namespace bp

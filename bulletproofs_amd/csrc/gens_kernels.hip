@@ -16,10 +16,10 @@
 namespace bp {
 
 // bases[p*W + w] = 2^(c*w) * P_p  (XYZZ); one thread per point (serial doubling chain).
-__global__ void k_gens_bases(const affine* __restrict__ pts, int np, int c, int W, xyzz* __restrict__ bases) {
+__global__ void k_gens_bases(const affine_mem* __restrict__ pts, int np, int c, int W, xyzz* __restrict__ bases) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= np) return;
-    xyzz acc = xyzz_from_affine(pts[p]);
+    xyzz acc = xyzz_from_affine(affine_load(pts[p]));
     bases[(size_t)p * W] = acc;
     for (int w = 1; w < W; w++) {
         for (int k = 0; k < c; k++) acc = xyzz_dbl(acc);
@@ -28,17 +28,17 @@ __global__ void k_gens_bases(const affine* __restrict__ pts, int np, int c, int 
 }
 
 // out[i] = affine(in[i]); one thread per element, one inversion each (small arrays only).
-__global__ void k_xyzz_to_affine(const xyzz* __restrict__ in, affine* __restrict__ out, size_t n) {
+__global__ void k_xyzz_to_affine(const xyzz* __restrict__ in, affine_mem* __restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = xyzz_to_affine(in[i]);
+    out[i] = affine_store(xyzz_to_affine(in[i]));
 }
 
 // tmp[idx*NB + d-1] = d * B_idx, d = 1..NB; one thread per idx = p*W + w.
-__global__ void k_gens_multiples(const affine* __restrict__ basesA, size_t nidx, int NB, xyzz* __restrict__ tmp) {
+__global__ void k_gens_multiples(const affine_mem* __restrict__ basesA, size_t nidx, int NB, xyzz* __restrict__ tmp) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nidx) return;
-    affine B = basesA[idx];
+    affine B = affine_load(basesA[idx]);
     xyzz acc = xyzz_from_affine(B);
     xyzz* dst = tmp + idx * (size_t)NB;
     dst[0] = acc;
@@ -51,7 +51,7 @@ __global__ void k_gens_multiples(const affine* __restrict__ basesA, size_t nidx,
 // Chunked batch normalisation: each thread converts CH consecutive XYZZ entries to affine with one
 // field inversion (Montgomery's trick on the ZZZ coordinates).  Entries must not be infinity.
 #define GENS_CH 16
-__global__ void k_gens_normalize(const xyzz* __restrict__ tmp, size_t n, affine* __restrict__ table) {
+__global__ void k_gens_normalize(const xyzz* __restrict__ tmp, size_t n, affine_mem* __restrict__ table) {
     size_t chunk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t i0 = chunk * GENS_CH;
     if (i0 >= n) return;
@@ -72,23 +72,23 @@ __global__ void k_gens_normalize(const xyzz* __restrict__ tmp, size_t n, affine*
         affine a;
         a.x = fp_mul(e.X, zi2);
         a.y = fp_mul(e.Y, zi3);
-        table[i0 + i] = a;
+        table[i0 + i] = affine_store(a);
     }
 }
 
-hipError_t launch_gens_bases(const affine* pts, int np, int c, int W, xyzz* bases, hipStream_t st) {
+hipError_t launch_gens_bases(const affine_mem* pts, int np, int c, int W, xyzz* bases, hipStream_t st) {
     hipLaunchKernelGGL(k_gens_bases, dim3((np + 63) / 64), dim3(64), 0, st, pts, np, c, W, bases);
     return hipGetLastError();
 }
-hipError_t launch_xyzz_to_affine(const xyzz* in, affine* out, size_t n, hipStream_t st) {
+hipError_t launch_xyzz_to_affine(const xyzz* in, affine_mem* out, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(k_xyzz_to_affine, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, in, out, n);
     return hipGetLastError();
 }
-hipError_t launch_gens_multiples(const affine* basesA, size_t nidx, int NB, xyzz* tmp, hipStream_t st) {
+hipError_t launch_gens_multiples(const affine_mem* basesA, size_t nidx, int NB, xyzz* tmp, hipStream_t st) {
     hipLaunchKernelGGL(k_gens_multiples, dim3((unsigned)((nidx + 63) / 64)), dim3(64), 0, st, basesA, nidx, NB, tmp);
     return hipGetLastError();
 }
-hipError_t launch_gens_normalize(const xyzz* tmp, size_t n, affine* table, hipStream_t st) {
+hipError_t launch_gens_normalize(const xyzz* tmp, size_t n, affine_mem* table, hipStream_t st) {
     size_t chunks = (n + GENS_CH - 1) / GENS_CH;
     hipLaunchKernelGGL(k_gens_normalize, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, st, tmp, n, table);
     return hipGetLastError();

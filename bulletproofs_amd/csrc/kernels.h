@@ -11,28 +11,29 @@ namespace bp {
 
 // msm_kernels.hip
 size_t msm_slice_lds_bytes(int c, int M, int T);
-hipError_t launch_ingest_points(const uint8_t* in_be, affine* out, size_t n, int* err, hipStream_t st);
-hipError_t launch_export_points(const affine* in, uint8_t* out_be, size_t n, hipStream_t st);
+hipError_t launch_ingest_points(const uint8_t* in_be, affine_mem* out, size_t n, int* err, hipStream_t st);
+hipError_t launch_export_points(const affine_mem* in, uint8_t* out_be, size_t n, hipStream_t st);
 hipError_t launch_scalars_to_digits(const uint8_t* scalars_be, size_t n, size_t npad, int c, int W, int16_t* digits, hipStream_t st);
-hipError_t launch_msm_slice(const affine* pts, const int16_t* digits, size_t n, size_t npad, int M, int c, int W, int S, int T, xyzz* partial,
+hipError_t launch_msm_slice(const affine_mem* pts, const int16_t* digits, size_t n, size_t npad, int M, int c, int W, int S, int T, xyzz* partial,
                             hipStream_t st);
 hipError_t launch_msm_reduce_slices(const xyzz* partial, int S, int W, xyzz* wsum, hipStream_t st);
-hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine* init, affine* out_limbs, uint8_t* out_be, hipStream_t st);
+hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine_mem* init, affine_mem* out_limbs, uint8_t* out_be, hipStream_t st);
 
 
 // gens_kernels.hip
-hipError_t launch_gens_bases(const affine* pts, int np, int c, int W, xyzz* bases, hipStream_t st);
-hipError_t launch_xyzz_to_affine(const xyzz* in, affine* out, size_t n, hipStream_t st);
-hipError_t launch_gens_multiples(const affine* basesA, size_t nidx, int NB, xyzz* tmp, hipStream_t st);
-hipError_t launch_gens_normalize(const xyzz* tmp, size_t n, affine* table, hipStream_t st);
+hipError_t launch_gens_bases(const affine_mem* pts, int np, int c, int W, xyzz* bases, hipStream_t st);
+hipError_t launch_xyzz_to_affine(const xyzz* in, affine_mem* out, size_t n, hipStream_t st);
+hipError_t launch_gens_multiples(const affine_mem* basesA, size_t nidx, int NB, xyzz* tmp, hipStream_t st);
+hipError_t launch_gens_normalize(const xyzz* tmp, size_t n, affine_mem* table, hipStream_t st);
 
 // verify_kernels.hip
-hipError_t launch_bpv_decompress(const uint8_t* proofs, size_t proof_len, const uint8_t* coms_xy, int k, int m, size_t nproofs, affine* pts,
+hipError_t launch_bpv_decompress(const uint8_t* proofs, size_t proof_len, const uint8_t* coms_xy, int k, int m, size_t nproofs, affine_mem* pts,
                                  int* bad, hipStream_t st);
-hipError_t launch_bpv_scalars(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine* pts,
-                              const affine* gens, const affine* table, int c, int W, int16_t* digF, fq* varS, fq* sbuf, int* bad,
+hipError_t launch_bpv_scalars(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
+                              const affine_mem* gens, const affine_mem* table, int c, int W, int16_t* digF, fq* varS, fq* sbuf, int* bad,
                               hipStream_t st);
-hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine* pts, const affine* table, int c, int W,
-                          const int16_t* digF, const fq* varS, const int* bad, uint8_t* verdicts, hipStream_t st);
+hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
+                          const int16_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st);
+size_t bpv_msm_vartab_bytes(int tp, size_t nproofs);
 
 }  // namespace bp

@@ -8,9 +8,10 @@
 // bucket in LDS and sum each bucket in registers (no atomics on group elements, no global sort)
 // -> in-LDS suffix-scan bucket reduction -> per-window slice reduction -> Horner combine.
 //
-// Data layout in HBM: points as `affine` (16 x u32 limbs, 64 B, one cache line per gather);
+// Data layout in HBM: points as `affine_mem` (canonical 8x32-bit words per coordinate, 64 B, one
+// cache line per gather; converted to the 9x29-bit compute form after the load);
 // digits as int16 [W][Npad] (window-major so a (slice, window) workgroup streams a contiguous,
-// coalesced run); partial sums as XYZZ (128 B).
+// coalesced run); partial sums as XYZZ in compute form (144 B).
 #include <hip/hip_runtime.h>
 
 #include "ec.h"
@@ -22,31 +23,30 @@ namespace bp {
 // ---------------------------------------------------------------------------------------------
 // ingest: 64-byte big-endian x||y -> limb form, with the on-curve check curv's Point::from_bytes
 // performs.  err: bit 0 set if any point is neither infinity (64 zero bytes) nor on the curve.
-__global__ void k_ingest_points(const uint8_t* __restrict__ in_be, affine* __restrict__ out, size_t n, int* err) {
+__global__ void k_ingest_points(const uint8_t* __restrict__ in_be, affine_mem* __restrict__ out, size_t n, int* err) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(in_be + 64 * i);
-    affine p;
+    affine_mem m;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        p.x.v[k] = __builtin_bswap32(src[7 - k]);
-        p.y.v[k] = __builtin_bswap32(src[15 - k]);
+        m.x.w[k] = __builtin_bswap32(src[7 - k]);
+        m.y.w[k] = __builtin_bswap32(src[15 - k]);
     }
-    bool ok = affine_is_inf(p) || (fp_is_canonical(p.x) && fp_is_canonical(p.y) && affine_on_curve(p));
-    if (!ok) atomicOr(err, 1);
-    out[i] = p;
+    if (!affine_mem_valid(m, true)) atomicOr(err, 1);
+    out[i] = m;
 }
 
 // limb form -> 64-byte big-endian (infinity -> 64 zero bytes)
-__global__ void k_export_points(const affine* __restrict__ in, uint8_t* __restrict__ out_be, size_t n) {
+__global__ void k_export_points(const affine_mem* __restrict__ in, uint8_t* __restrict__ out_be, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    affine p = in[i];
+    affine_mem m = in[i];
     uint32_t* dst = reinterpret_cast<uint32_t*>(out_be + 64 * i);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        dst[7 - k] = __builtin_bswap32(p.x.v[k]);
-        dst[15 - k] = __builtin_bswap32(p.y.v[k]);
+        dst[7 - k] = __builtin_bswap32(m.x.w[k]);
+        dst[15 - k] = __builtin_bswap32(m.y.w[k]);
     }
 }
 
@@ -105,7 +105,7 @@ __global__ void k_scalars_to_digits(const uint8_t* __restrict__ scalars_be, size
 //      Hillis-Steele suffix scan followed by a tree reduction (r is a power of two -> doublings).
 // LDS: 2*(NB+1) u32 + M u16 + T XYZZ.
 template <int T>
-__global__ __launch_bounds__(T) void k_msm_slice(const affine* __restrict__ pts, const int16_t* __restrict__ digits, size_t n, size_t npad,
+__global__ __launch_bounds__(T) void k_msm_slice(const affine_mem* __restrict__ pts, const int16_t* __restrict__ digits, size_t n, size_t npad,
                                                  int M, int c, xyzz* __restrict__ partial /* [W][S] */) {
     extern __shared__ __align__(16) uint8_t smem_raw[];
     const int NB = 1 << (c - 1);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(T) void k_msm_slice(const affine* __restrict__ pts,
             uint32_t j0 = start[b], j1 = start[b + 1];
             for (uint32_t j = j0; j < j1; j++) {
                 uint32_t e = sorted[j];
-                affine p = pts[base + (e & 0x7fff)];
+                affine p = affine_load(pts[base + (e & 0x7fff)]);
                 if (e & 0x8000) p.y = fp_neg(p.y);
                 xyzz_madd(B, p);
             }
@@ -222,9 +222,9 @@ __global__ __launch_bounds__(T) void k_msm_slice(const affine* __restrict__ pts,
     if (tid == 0) partial[(size_t)w * S + slice] = red[0];
 }
 
-template __global__ void k_msm_slice<64>(const affine*, const int16_t*, size_t, size_t, int, int, xyzz*);
-template __global__ void k_msm_slice<128>(const affine*, const int16_t*, size_t, size_t, int, int, xyzz*);
-template __global__ void k_msm_slice<256>(const affine*, const int16_t*, size_t, size_t, int, int, xyzz*);
+template __global__ void k_msm_slice<64>(const affine_mem*, const int16_t*, size_t, size_t, int, int, xyzz*);
+template __global__ void k_msm_slice<128>(const affine_mem*, const int16_t*, size_t, size_t, int, int, xyzz*);
+template __global__ void k_msm_slice<256>(const affine_mem*, const int16_t*, size_t, size_t, int, int, xyzz*);
 
 // ---------------------------------------------------------------------------------------------
 // wsum[w] = sum over slices of partial[w][s]; one 64-lane workgroup per window.
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64) void k_msm_reduce_slices(const xyzz* __restrict
 
 // result = init + sum_w 2^(c*w) wsum[w]  (Horner, one lane: the doubling chain is inherently serial),
 // normalised to the canonical affine element and written as 64 big-endian bytes.
-__global__ void k_msm_horner(const xyzz* __restrict__ wsum, int W, int c, const affine* __restrict__ init, affine* __restrict__ out_limbs,
+__global__ void k_msm_horner(const xyzz* __restrict__ wsum, int W, int c, const affine_mem* __restrict__ init, affine_mem* __restrict__ out_limbs,
                              uint8_t* __restrict__ out_be) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     xyzz acc = wsum[W - 1];
@@ -261,15 +261,15 @@ __global__ void k_msm_horner(const xyzz* __restrict__ wsum, int W, int c, const 
         xyzz o = wsum[w];
         xyzz_add(acc, o);
     }
-    if (init) xyzz_madd(acc, *init);
-    affine a = xyzz_to_affine(acc);
-    if (out_limbs) *out_limbs = a;
+    if (init) xyzz_madd(acc, affine_load(*init));
+    affine_mem m = affine_store(xyzz_to_affine(acc));
+    if (out_limbs) *out_limbs = m;
     if (out_be) {
         uint32_t* dst = reinterpret_cast<uint32_t*>(out_be);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            dst[7 - k] = __builtin_bswap32(a.x.v[k]);
-            dst[15 - k] = __builtin_bswap32(a.y.v[k]);
+            dst[7 - k] = __builtin_bswap32(m.x.w[k]);
+            dst[15 - k] = __builtin_bswap32(m.y.w[k]);
         }
     }
 }
@@ -281,12 +281,12 @@ size_t msm_slice_lds_bytes(int c, int M, int T) {
     return (size_t)T * sizeof(xyzz) + (size_t)2 * (NB + 1) * 4 + (size_t)M * 2;
 }
 
-hipError_t launch_ingest_points(const uint8_t* in_be, affine* out, size_t n, int* err, hipStream_t st) {
+hipError_t launch_ingest_points(const uint8_t* in_be, affine_mem* out, size_t n, int* err, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_ingest_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in_be, out, n, err);
     return hipGetLastError();
 }
-hipError_t launch_export_points(const affine* in, uint8_t* out_be, size_t n, hipStream_t st) {
+hipError_t launch_export_points(const affine_mem* in, uint8_t* out_be, size_t n, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_export_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out_be, n);
     return hipGetLastError();
@@ -295,7 +295,7 @@ hipError_t launch_scalars_to_digits(const uint8_t* scalars_be, size_t n, size_t 
     hipLaunchKernelGGL(k_scalars_to_digits, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st, scalars_be, n, npad, c, W, digits);
     return hipGetLastError();
 }
-hipError_t launch_msm_slice(const affine* pts, const int16_t* digits, size_t n, size_t npad, int M, int c, int W, int S, int T, xyzz* partial,
+hipError_t launch_msm_slice(const affine_mem* pts, const int16_t* digits, size_t n, size_t npad, int M, int c, int W, int S, int T, xyzz* partial,
                             hipStream_t st) {
     size_t lds = msm_slice_lds_bytes(c, M, T);
     dim3 grid((unsigned)S, (unsigned)W);
@@ -311,7 +311,7 @@ hipError_t launch_msm_reduce_slices(const xyzz* partial, int S, int W, xyzz* wsu
     hipLaunchKernelGGL(k_msm_reduce_slices, dim3((unsigned)W), dim3(64), 0, st, partial, S, wsum);
     return hipGetLastError();
 }
-hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine* init, affine* out_limbs, uint8_t* out_be, hipStream_t st) {
+hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine_mem* init, affine_mem* out_limbs, uint8_t* out_be, hipStream_t st) {
     hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(64), 0, st, wsum, W, c, init, out_limbs, out_be);
     return hipGetLastError();
 }

@@ -25,8 +25,8 @@ struct bp_gens {
     size_t nm = 0;
     int np = 0;       // 2nm + 2
     int c = 0, W = 0, NB = 0;
-    affine* d_pts = nullptr;    // g_vec, h_vec, G, H (limb form)
-    affine* d_table = nullptr;  // [np][W][NB]
+    affine_mem* d_pts = nullptr;    // g_vec, h_vec, G, H (limb form)
+    affine_mem* d_table = nullptr;  // [np][W][NB]
     size_t table_bytes = 0;
 };
 
@@ -61,10 +61,10 @@ int bp_gens_create(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t
     g->W = W;
     g->NB = NB;
     size_t nidx = (size_t)np * W, nent = nidx * NB;
-    g->table_bytes = nent * sizeof(affine);
+    g->table_bytes = nent * sizeof(affine_mem);
     uint8_t* d_be = nullptr;
     xyzz *d_bases = nullptr, *d_tmp = nullptr;
-    affine* d_basesA = nullptr;
+    affine_mem* d_basesA = nullptr;
     int rc = BP_OK;
     std::vector<uint8_t> host((size_t)np * 64);
     memcpy(host.data(), g_xy, nm * 64);
@@ -89,10 +89,10 @@ int bp_gens_create(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t
         }                                   \
     }
     GCHK(hipMalloc((void**)&d_be, (size_t)np * 64));
-    GCHK(hipMalloc((void**)&g->d_pts, (size_t)np * sizeof(affine)));
+    GCHK(hipMalloc((void**)&g->d_pts, (size_t)np * sizeof(affine_mem)));
     GCHK(hipMalloc((void**)&g->d_table, g->table_bytes));
     GCHK(hipMalloc((void**)&d_bases, nidx * sizeof(xyzz)));
-    GCHK(hipMalloc((void**)&d_basesA, nidx * sizeof(affine)));
+    GCHK(hipMalloc((void**)&d_basesA, nidx * sizeof(affine_mem)));
     GCHK(hipMalloc((void**)&d_tmp, nent * sizeof(xyzz)));
     GCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), st));
     GCHK(hipMemcpyAsync(d_be, host.data(), (size_t)np * 64, hipMemcpyHostToDevice, st));
@@ -208,7 +208,7 @@ int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bi
     const int NPT = 4 + 2 * k + m, NV = 3 + 2 * k + m;
     int rc;
     DevBuf &b_pts = ctx->scratch[0], &b_bad = ctx->scratch[1], &b_dig = ctx->scratch[2], &b_var = ctx->scratch[3], &b_s = ctx->scratch[4];
-    if ((rc = b_pts.reserve(nproofs * NPT * sizeof(affine))) != BP_OK) return rc;
+    if ((rc = b_pts.reserve(nproofs * NPT * sizeof(affine_mem))) != BP_OK) return rc;
     if ((rc = b_bad.reserve(nproofs * sizeof(int))) != BP_OK) return rc;
     if ((rc = b_dig.reserve(nproofs * (size_t)gens->np * gens->W * sizeof(int16_t))) != BP_OK) return rc;
     if ((rc = b_var.reserve(nproofs * NV * sizeof(fq))) != BP_OK) return rc;
@@ -219,17 +219,18 @@ int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bi
         prof_collect(ctx);
     }
     prof_mark(ctx, 0);
-    HIPCHK(launch_bpv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine*)b_pts.p, (int*)b_bad.p, st),
+    HIPCHK(launch_bpv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine_mem*)b_pts.p, (int*)b_bad.p, st),
            "bpv_decompress");
     prof_mark(ctx, 1);
-    HIPCHK(launch_bpv_scalars((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine*)b_pts.p, gens->d_pts, gens->d_table,
+    HIPCHK(launch_bpv_scalars((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts, gens->d_table,
                               gens->c, gens->W, (int16_t*)b_dig.p, (fq*)b_var.p, (fq*)b_s.p, (int*)b_bad.p, st),
            "bpv_scalars");
     prof_mark(ctx, 2);
     int tp = ctx->verify_lanes ? ctx->verify_lanes : 16;
     if (tp != 16 && tp != 32 && tp != 64) tp = 16;
-    HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, (const affine*)b_pts.p, gens->d_table, gens->c, gens->W, (const int16_t*)b_dig.p,
-                          (const fq*)b_var.p, (const int*)b_bad.p, (uint8_t*)d_verdicts, st),
+    if ((rc = ctx->vartab.reserve(bpv_msm_vartab_bytes(tp, nproofs))) != BP_OK) return rc;
+    HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_table, gens->c, gens->W, (const int16_t*)b_dig.p,
+                          (const fq*)b_var.p, (xyzz*)ctx->vartab.p, (const int*)b_bad.p, (uint8_t*)d_verdicts, st),
            "bpv_msm");
     prof_mark(ctx, 3);
     if (ctx->profiling) {

@@ -26,7 +26,7 @@ namespace bp {
 
 // ------------------------------------------------------------------------------------------------
 __global__ void k_bpv_decompress(const uint8_t* __restrict__ proofs, size_t proof_len, const uint8_t* __restrict__ coms_xy, int k, int m,
-                                 size_t nproofs, affine* __restrict__ pts, int* __restrict__ bad) {
+                                 size_t nproofs, affine_mem* __restrict__ pts, int* __restrict__ bad) {
     const int npc = 4 + 2 * k;      // compressed points in a proof
     const int NPT = npc + m;        // + commitments
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -47,10 +47,11 @@ __global__ void k_bpv_decompress(const uint8_t* __restrict__ proofs, size_t proo
         const uint8_t* src = coms_xy + (pr * (size_t)m + (j - npc)) * 64;
         uint8_t b[64];
         for (int i = 0; i < 64; i++) b[i] = src[i];
-        a = affine_from_be64(b);
-        ok = fp_is_canonical(a.x) && fp_is_canonical(a.y) && affine_on_curve(a);  // infinity is not a valid commitment encoding
+        affine_mem mm = affine_mem_from_be64(b);
+        ok = affine_mem_valid(mm, false);  // infinity is not a valid commitment encoding
+        a = ok ? affine_load(mm) : affine_inf();
     }
-    pts[pr * NPT + j] = a;
+    pts[pr * NPT + j] = affine_store(a);
     if (!ok) atomicOr(&bad[pr], 1);
 }
 
@@ -80,7 +81,7 @@ __device__ __forceinline__ fq tr_result_scalar(const sha256_ctx& c) {
 }
 
 // k * G from the generator table (G is fixed point index pG): W gathers + mixed adds, normalised.
-__device__ __forceinline__ affine fixed_mul_table(const affine* __restrict__ table, int pG, int c, int W, const fq& k) {
+__device__ __forceinline__ affine fixed_mul_table(const affine_mem* __restrict__ table, int pG, int c, int W, const fq& k) {
     const int NB = 1 << (c - 1);
     // recode (same signed-digit rule as recode_signed in msm_kernels.hip)
     uint32_t carry = 0;
@@ -105,7 +106,7 @@ __device__ __forceinline__ affine fixed_mul_table(const affine* __restrict__ tab
             carry = 0;
         }
         if (d != 0) {
-            affine e = table[((size_t)pG * W + w) * NB + ((d < 0 ? -d : d) - 1)];
+            affine e = affine_load(table[((size_t)pG * W + w) * NB + ((d < 0 ? -d : d) - 1)]);
             if (d < 0) e.y = fp_neg(e.y);
             xyzz_madd(acc, e);
         }
@@ -145,8 +146,8 @@ __device__ __forceinline__ void store_digits(const fq& k, int c, int W, int16_t*
 //   varS  [proof][NV]           plain scalars of S, L_j, R_j, V_j, T1, T2 (NV = 3 + 2k + m)
 //   sbuf  [proof][nm]           scratch (Montgomery s_i, range_proof.rs:670-680)
 __global__ __launch_bounds__(64) void k_bpv_scalars(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
-                                                    const affine* __restrict__ pts, const affine* __restrict__ gens /* g,h,G,H */,
-                                                    const affine* __restrict__ table, int c, int W, int16_t* __restrict__ digF,
+                                                    const affine_mem* __restrict__ pts, const affine_mem* __restrict__ gens /* g,h,G,H */,
+                                                    const affine_mem* __restrict__ table, int c, int W, int16_t* __restrict__ digF,
                                                     fq* __restrict__ varS, fq* __restrict__ sbuf, int* __restrict__ bad) {
     size_t pr = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pr >= nproofs) return;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(64) void k_bpv_scalars(const uint8_t* __restrict__ 
     const int NPT = 4 + 2 * k + m;
     const int NV = 3 + 2 * k + m;
     const int pG = 2 * nm, pH = 2 * nm + 1;
-    const affine* P = pts + pr * NPT;
+    const affine_mem* P = pts + pr * NPT;
     const uint8_t* pf = proofs + pr * proof_len;
     const uint8_t* sc = pf + 4 * 33;                         // tau_x, miu, tx
     const uint8_t* ab = pf + 4 * 33 + 96 + (size_t)66 * k;   // a_tag, b_tag
@@ -166,8 +167,8 @@ __global__ __launch_bounds__(64) void k_bpv_scalars(const uint8_t* __restrict__ 
         atomicOr(&bad[pr], 1);
         return;
     }
-    const affine A = P[0], S = P[1], T1 = P[2], T2 = P[3];
-    const affine Gp = gens[pG], Hp = gens[pH];
+    const affine A = affine_load(P[0]), S = affine_load(P[1]), T1 = affine_load(P[2]), T2 = affine_load(P[3]);
+    const affine Gp = affine_load(gens[pG]), Hp = affine_load(gens[pH]);
 
     sha256_ctx h;
     // y = H(A, S)                                                     range_proof.rs:565-567
@@ -225,8 +226,8 @@ __global__ __launch_bounds__(64) void k_bpv_scalars(const uint8_t* __restrict__ 
     bool zero_ch = fq_is_zero(y);
     for (int j = 0; j < k; j++) {
         sha256_init(h);
-        tr_point(h, P[4 + j]);
-        tr_point(h, P[4 + k + j]);
+        tr_point(h, affine_load(P[4 + j]));
+        tr_point(h, affine_load(P[4 + k + j]));
         tr_point(h, ux);
         fq xv = tr_result_scalar(h);
         zero_ch = zero_ch || fq_is_zero(xv);
@@ -306,30 +307,49 @@ __global__ __launch_bounds__(64) void k_bpv_scalars(const uint8_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k * P for one variable point: NAF double-and-add (no table), MSB first.  NAF(k) = (3k xor k) >> 1.
-__device__ __forceinline__ xyzz naf_mul(const affine& P, const fq& k) {
-    // h = 3k (up to 258 bits)
-    uint32_t h[9], kk[9];
-    uint64_t cy = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        cy += (uint64_t)k.v[i] * 3u;
-        h[i] = (uint32_t)cy;
-        cy >>= 32;
-        kk[i] = k.v[i];
+// k * P for one variable point: fixed 4-bit signed windows (digits in [-8, 8], 65 windows), with the
+// multiples 1P..8P kept as XYZZ in a lane-private slice of a global scratch buffer.  Control flow is
+// uniform across the wave (4 doublings + 1 addition per window for every lane): a NAF
+// double-and-add would make every lane wait on both the +P and the -P branch at almost every bit.
+#define VAR_WBITS 4
+#define VAR_NT 8  // table entries
+__device__ __forceinline__ xyzz window_mul(const affine& P, const fq& k, xyzz* __restrict__ tab) {
+    if (affine_is_inf(P)) return xyzz_inf();
+    xyzz t = xyzz_from_affine(P);
+    tab[0] = t;
+    t = xyzz_dbl_affine(P);
+    tab[1] = t;
+    for (int i = 2; i < VAR_NT; i++) {
+        xyzz_madd(t, P);
+        tab[i] = t;
     }
-    h[8] = (uint32_t)cy;
-    kk[8] = 0;
+    // signed digits, most significant window first; recode on the fly from the top:
+    // d_w = bits(w) + carry_in(w) - 16*carry_out(w) needs the carries from below, so precompute them.
+    // carry into window w+1 is 1 iff (bits(w) + carry(w)) > 8.
+    uint32_t cmask[3] = {0, 0, 0};  // carry-in bit per window (65 windows)
+    {
+        uint32_t carry = 0;
+        for (int w = 0; w < 64; w++) {
+            uint32_t v = ((k.v[w >> 3] >> ((w & 7) * 4)) & 15u) + carry;
+            carry = v > 8u ? 1u : 0u;
+            if (carry) cmask[(w + 1) >> 5] |= 1u << ((w + 1) & 31);
+        }
+    }
     xyzz acc = xyzz_inf();
-    affine Pn = affine_neg(P);
-    for (int i = 257; i >= 1; i--) {
-        acc = xyzz_dbl(acc);
-        uint32_t hb = (h[i >> 5] >> (i & 31)) & 1u, kb = (kk[i >> 5] >> (i & 31)) & 1u;
-        if (hb != kb) {
-            if (hb)
-                xyzz_madd(acc, P);
-            else
-                xyzz_madd(acc, Pn);
+    for (int w = 64; w >= 0; w--) {
+        if (w != 64) {
+            acc = xyzz_dbl(acc);
+            acc = xyzz_dbl(acc);
+            acc = xyzz_dbl(acc);
+            acc = xyzz_dbl(acc);
+        }
+        uint32_t bits = (w < 64) ? ((k.v[w >> 3] >> ((w & 7) * 4)) & 15u) : 0u;
+        uint32_t v = bits + ((cmask[w >> 5] >> (w & 31)) & 1u);
+        int d = v > 8u ? (int)v - 16 : (int)v;
+        if (d != 0) {
+            xyzz e = tab[(d < 0 ? -d : d) - 1];
+            if (d < 0) e.Y = fp_neg(e.Y);
+            xyzz_add(acc, e);
         }
     }
     return acc;
@@ -337,9 +357,10 @@ __device__ __forceinline__ xyzz naf_mul(const affine& P, const fq& k) {
 
 // TP lanes per proof; 256-thread workgroups.
 template <int TP>
-__global__ __launch_bounds__(256) void k_bpv_msm(int n_bits, int m, int k, size_t nproofs, const affine* __restrict__ pts,
-                                                 const affine* __restrict__ table, int c, int W, const int16_t* __restrict__ digF,
-                                                 const fq* __restrict__ varS, const int* __restrict__ bad, uint8_t* __restrict__ verdicts) {
+__global__ __launch_bounds__(256) void k_bpv_msm(int n_bits, int m, int k, size_t nproofs, const affine_mem* __restrict__ pts,
+                                                 const affine_mem* __restrict__ table, int c, int W, const int16_t* __restrict__ digF,
+                                                 const fq* __restrict__ varS, xyzz* __restrict__ vartab, const int* __restrict__ bad,
+                                                 uint8_t* __restrict__ verdicts) {
     __shared__ xyzz red[256];
     const int tid = threadIdx.x;
     const int lane = tid % TP;
@@ -356,17 +377,17 @@ __global__ __launch_bounds__(256) void k_bpv_msm(int n_bits, int m, int k, size_
         for (int idx = lane; idx < nfw; idx += TP) {
             int d = dg[idx];
             if (d != 0) {
-                affine e = table[(size_t)idx * NB + ((d < 0 ? -d : d) - 1)];
+                affine e = affine_load(table[(size_t)idx * NB + ((d < 0 ? -d : d) - 1)]);
                 if (d < 0) e.y = fp_neg(e.y);
                 xyzz_madd(acc, e);
             }
         }
-        const affine* P = pts + pr * NPT;
+        const affine_mem* P = pts + pr * NPT;
         const fq* vs = varS + pr * (size_t)NV;
         for (int v = lane; v < NV; v += TP) {
             // variable point order: S, L_0.., R_0.., V_0.., T1, T2  ->  index into pts
             int pi = (v == 0) ? 1 : (v < 1 + 2 * k + m) ? (3 + v) : (v == 1 + 2 * k + m ? 2 : 3);
-            xyzz t = naf_mul(P[pi], vs[v]);
+            xyzz t = window_mul(affine_load(P[pi]), vs[v], vartab + ((size_t)blockIdx.x * 256 + tid) * VAR_NT);
             xyzz_add(acc, t);
         }
     }
@@ -388,7 +409,7 @@ __global__ __launch_bounds__(256) void k_bpv_msm(int n_bits, int m, int k, size_
         } else {
             // lhs == A ?  (range_proof.rs:777) compared projectively: X = A.x*ZZ, Y = A.y*ZZZ
             xyzz r = red[tid];
-            affine A = pts[pr * NPT];
+            affine A = affine_load(pts[pr * NPT]);
             bool eq = !xyzz_is_inf(r) && fp_eq(r.X, fp_mul(A.x, r.ZZ)) && fp_eq(r.Y, fp_mul(A.y, r.ZZZ));
             verdict = eq ? 0 : 3;
         }
@@ -396,29 +417,33 @@ __global__ __launch_bounds__(256) void k_bpv_msm(int n_bits, int m, int k, size_
     }
 }
 
-hipError_t launch_bpv_decompress(const uint8_t* proofs, size_t proof_len, const uint8_t* coms_xy, int k, int m, size_t nproofs, affine* pts,
+hipError_t launch_bpv_decompress(const uint8_t* proofs, size_t proof_len, const uint8_t* coms_xy, int k, int m, size_t nproofs, affine_mem* pts,
                                  int* bad, hipStream_t st) {
     size_t total = nproofs * (size_t)(4 + 2 * k + m);
     hipLaunchKernelGGL(k_bpv_decompress, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, proofs, proof_len, coms_xy, k, m, nproofs, pts,
                        bad);
     return hipGetLastError();
 }
-hipError_t launch_bpv_scalars(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine* pts,
-                              const affine* gens, const affine* table, int c, int W, int16_t* digF, fq* varS, fq* sbuf, int* bad,
+hipError_t launch_bpv_scalars(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
+                              const affine_mem* gens, const affine_mem* table, int c, int W, int16_t* digF, fq* varS, fq* sbuf, int* bad,
                               hipStream_t st) {
     hipLaunchKernelGGL(k_bpv_scalars, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, pts, gens,
                        table, c, W, digF, varS, sbuf, bad);
     return hipGetLastError();
 }
-hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine* pts, const affine* table, int c, int W,
-                          const int16_t* digF, const fq* varS, const int* bad, uint8_t* verdicts, hipStream_t st) {
+size_t bpv_msm_vartab_bytes(int tp, size_t nproofs) {
+    size_t blocks = (nproofs + (256 / tp) - 1) / (256 / tp);
+    return blocks * 256 * VAR_NT * sizeof(xyzz);
+}
+hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
+                          const int16_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st) {
     unsigned blocks = (unsigned)((nproofs + (256 / tp) - 1) / (256 / tp));
     if (tp == 16)
-        hipLaunchKernelGGL(k_bpv_msm<16>, dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, bad, verdicts);
+        hipLaunchKernelGGL(k_bpv_msm<16>, dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, bad, verdicts);
     else if (tp == 32)
-        hipLaunchKernelGGL(k_bpv_msm<32>, dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, bad, verdicts);
+        hipLaunchKernelGGL(k_bpv_msm<32>, dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, bad, verdicts);
     else
-        hipLaunchKernelGGL(k_bpv_msm<64>, dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, bad, verdicts);
+        hipLaunchKernelGGL(k_bpv_msm<64>, dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, bad, verdicts);
     return hipGetLastError();
 }
 
