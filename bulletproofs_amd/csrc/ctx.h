@@ -46,7 +46,7 @@ struct bp_ctx {
     std::mutex mu;
     bp::DevBuf in_points_be, in_scalars_be, points, digits, partial, wsum, result, initbuf;
     bp::DevBuf scratch[8];
-    bp::DevBuf vartab;
+    bp::DevBuf vartab, fixres;
     void release_all() {
         in_points_be.release();
         in_scalars_be.release();
@@ -58,6 +58,7 @@ struct bp_ctx {
         initbuf.release();
         for (auto& s : scratch) s.release();
         vartab.release();
+        fixres.release();
     }
 };
 

@@ -29,9 +29,12 @@ hipError_t launch_gens_normalize(const xyzz* tmp, size_t n, affine_mem* table, h
 // verify_kernels.hip
 hipError_t launch_bpv_decompress(const uint8_t* proofs, size_t proof_len, const uint8_t* coms_xy, int k, int m, size_t nproofs, affine_mem* pts,
                                  int* bad, hipStream_t st);
-hipError_t launch_bpv_scalars(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
-                              const affine_mem* gens, const affine_mem* table, int c, int W, int16_t* digF, fq* varS, fq* sbuf, int* bad,
-                              hipStream_t st);
+// verify_scalars.hip
+size_t bpv_chal_count(int k);
+size_t bpv_cst_count(int k, int m);
+hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
+                                      const affine_mem* gens, const affine_mem* table, int c, int W, int16_t* digF, fq* varS, fq* chal,
+                                      fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st);
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
                           const int16_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st);
 size_t bpv_msm_vartab_bytes(int tp, size_t nproofs);

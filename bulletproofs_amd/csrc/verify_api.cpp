@@ -188,7 +188,7 @@ int bp_profile_get(bp_ctx* ctx, int kernel_id, double* total_ms, long* launches)
 
 int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
                                       const void* d_coms_xy, size_t nproofs, void* d_verdicts) {
-    if (!ctx || !gens || n_bits <= 0 || m <= 0) return BP_EINVAL;
+    if (!ctx || !gens || n_bits <= 0 || n_bits > 128 || m <= 0) return BP_EINVAL;
     if (nproofs == 0) return BP_OK;
     if (!d_proofs || !d_coms_xy || !d_verdicts) return BP_EINVAL;
     size_t nm = (size_t)n_bits * m;
@@ -212,7 +212,12 @@ int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bi
     if ((rc = b_bad.reserve(nproofs * sizeof(int))) != BP_OK) return rc;
     if ((rc = b_dig.reserve(nproofs * (size_t)gens->np * gens->W * sizeof(int16_t))) != BP_OK) return rc;
     if ((rc = b_var.reserve(nproofs * NV * sizeof(fq))) != BP_OK) return rc;
-    if ((rc = b_s.reserve(nproofs * nm * sizeof(fq))) != BP_OK) return rc;
+    if ((rc = b_s.reserve(nproofs * (bpv_chal_count(k) + bpv_cst_count(k, m)) * sizeof(fq))) != BP_OK) return rc;
+    if ((rc = ctx->fixres.reserve(nproofs * 2 * (sizeof(xyzz) + sizeof(affine_mem)))) != BP_OK) return rc;
+    fq* d_chal = (fq*)b_s.p;
+    fq* d_cst = d_chal + nproofs * bpv_chal_count(k);
+    xyzz* d_fixres = (xyzz*)ctx->fixres.p;
+    affine_mem* d_fixaff = (affine_mem*)(d_fixres + nproofs * 2);
     HIPCHK(hipMemsetAsync(b_bad.p, 0, nproofs * sizeof(int), st), "memset");
     if (ctx->profiling && ctx->prof_n) {  // previous call not collected yet: drain it first
         HIPCHK(hipStreamSynchronize(st), "sync");
@@ -222,8 +227,9 @@ int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bi
     HIPCHK(launch_bpv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine_mem*)b_pts.p, (int*)b_bad.p, st),
            "bpv_decompress");
     prof_mark(ctx, 1);
-    HIPCHK(launch_bpv_scalars((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts, gens->d_table,
-                              gens->c, gens->W, (int16_t*)b_dig.p, (fq*)b_var.p, (fq*)b_s.p, (int*)b_bad.p, st),
+    HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
+                                      gens->d_table, gens->c, gens->W, (int16_t*)b_dig.p, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
+                                      (int*)b_bad.p, st),
            "bpv_scalars");
     prof_mark(ctx, 2);
     int tp = ctx->verify_lanes ? ctx->verify_lanes : 16;

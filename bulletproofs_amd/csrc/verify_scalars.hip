@@ -1,0 +1,465 @@
+// Scalar side of the batched `RangeProof::aggregated_verify`
+// (/root/reference/src/proofs/range_proof.rs:565-740), split into short kernels whose launch shape
+// matches the parallelism each step really has (the reference does all of it on one thread):
+//
+//   k_bpv_hash1  4 lanes/proof   y = H(A,S), x = H(T1,T2,G,H), x_u = H(tau_x,miu,tx), c = H(A,S,T1,T2,G,H)
+//   k_bpv_fixmul 16 lanes/proof  y*G and x_u*G (:571, :588) from the generator table, 8 lanes each
+//   k_bpv_fixinv 1 lane/proof    one shared field inversion -> affine yG, ux (needed as hash input)
+//   k_bpv_hash2  k+1 lanes/proof z = H(yG), x_j = H(L_j, R_j, ux)                         (:572, :656)
+//   k_bpv_consts 1 lane/proof    one batched inversion mod q for y, y-1, x_j; delta; scalars of
+//                                G, H, S, L_j, R_j, V_j, T1, T2                          (:639-740)
+//   k_bpv_vec    1 lane/(proof,i) g_i and h_i scalars (:682-705) -> signed window digits
+//
+// SHA-256 messages are assembled byte-wise in LDS (per-lane slots) and compressed from registers.
+#include <hip/hip_runtime.h>
+
+#include "ec.h"
+#include "fq.h"
+#include "kernels.h"
+#include "sha256.h"
+
+namespace bp {
+
+// ------------------------------------------------------------------------------------------------
+// LDS-staged SHA-256 of a short message (<= 440 bytes incl. the 4-byte try-and-increment counter).
+#define MSG_MAX 448
+#define MSG_STRIDE 452  // odd number of words per lane slot: conflict-free lane-strided access
+
+__device__ __forceinline__ void msg_put(uint8_t* buf, int& pos, uint8_t b) { buf[pos++] = b; }
+__device__ __forceinline__ void msg_put_words_be(uint8_t* buf, int& pos, const fp_words& w) {
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        uint32_t v = w.w[i];
+        buf[pos] = (uint8_t)(v >> 24);
+        buf[pos + 1] = (uint8_t)(v >> 16);
+        buf[pos + 2] = (uint8_t)(v >> 8);
+        buf[pos + 3] = (uint8_t)v;
+        pos += 4;
+    }
+}
+// chain_points: 0x04 || X || Y  (curv `to_bytes(false)`)
+__device__ __forceinline__ void msg_put_point(uint8_t* buf, int& pos, const affine_mem& p) {
+    msg_put(buf, pos, 4);
+    msg_put_words_be(buf, pos, p.x);
+    msg_put_words_be(buf, pos, p.y);
+}
+// chain_bigint: minimal big-endian magnitude (zero -> one 0x00 byte)
+__device__ __forceinline__ void msg_put_bigint32(uint8_t* buf, int& pos, const uint8_t* be32) {
+    int i = 0;
+    while (i < 31 && be32[i] == 0) i++;
+    for (; i < 32; i++) buf[pos++] = be32[i];
+}
+
+__device__ __forceinline__ void sha256_compress_words(uint32_t h[8], uint32_t w[16]) {
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        uint32_t wi;
+        if (i < 16) {
+            wi = w[i];
+        } else {
+            uint32_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+            uint32_t s0 = sha256_rotr(w15, 7) ^ sha256_rotr(w15, 18) ^ (w15 >> 3);
+            uint32_t s1 = sha256_rotr(w2, 17) ^ sha256_rotr(w2, 19) ^ (w2 >> 10);
+            wi = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
+            w[i & 15] = wi;
+        }
+        uint32_t S1 = sha256_rotr(e, 6) ^ sha256_rotr(e, 11) ^ sha256_rotr(e, 25);
+        uint32_t ch = (e & f) ^ (~e & g);
+        uint32_t t1 = hh + S1 + ch + SHA256_K_DEV[i] + wi;
+        uint32_t S0 = sha256_rotr(a, 2) ^ sha256_rotr(a, 13) ^ sha256_rotr(a, 22);
+        uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+        uint32_t t2 = S0 + mj;
+        hh = g;
+        g = f;
+        f = e;
+        e = d + t1;
+        d = c;
+        c = b;
+        b = a;
+        a = t1 + t2;
+    }
+    h[0] += a;
+    h[1] += b;
+    h[2] += c;
+    h[3] += d;
+    h[4] += e;
+    h[5] += f;
+    h[6] += g;
+    h[7] += hh;
+}
+
+// result_scalar (curv DigestExt, try-and-increment): H(msg || be32(i)), i = 0, 1, ..; first digest < q.
+// `len` = message length without the counter.  buf must have room for len + 4 + 73 bytes.
+__device__ __forceinline__ fq msg_result_scalar(uint8_t* buf, int len) {
+    for (uint32_t ctr = 0;; ctr++) {
+        int pos = len;
+        buf[pos++] = (uint8_t)(ctr >> 24);
+        buf[pos++] = (uint8_t)(ctr >> 16);
+        buf[pos++] = (uint8_t)(ctr >> 8);
+        buf[pos++] = (uint8_t)ctr;
+        const uint32_t bits = (uint32_t)pos * 8u;
+        buf[pos++] = 0x80;
+        while ((pos & 63) != 56) buf[pos++] = 0;
+        buf[pos++] = 0;
+        buf[pos++] = 0;
+        buf[pos++] = 0;
+        buf[pos++] = 0;
+        buf[pos++] = (uint8_t)(bits >> 24);
+        buf[pos++] = (uint8_t)(bits >> 16);
+        buf[pos++] = (uint8_t)(bits >> 8);
+        buf[pos++] = (uint8_t)bits;
+        uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+        const int nblk = pos >> 6;
+        for (int blk = 0; blk < nblk; blk++) {
+            uint32_t w[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint8_t* q = buf + blk * 64 + i * 4;
+                w[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+            }
+            sha256_compress_words(h, w);
+        }
+        fq r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = h[7 - i];
+        uint32_t t[8];
+        if (fq_sub_q(t, r.v) == 1) return r;  // digest < q
+    }
+}
+
+// proof byte layout (oracle/encoding.py): A S T1 T2 | tau_x miu tx | L[k] | R[k] | a b
+#define PF_SCALARS (4 * 33)
+#define PF_AB(k) (4 * 33 + 96 + 66 * (k))
+
+// per-proof challenge slots (plain fq)
+#define CH_Y 0
+#define CH_X 1
+#define CH_XU 2
+#define CH_C 3
+#define CH_Z 4
+#define CH_XJ 5  // k entries
+#define CH_COUNT(k) (5 + (k))
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_bpv_hash1(const uint8_t* __restrict__ proofs, size_t proof_len, int k, int m, int nm, size_t nproofs,
+                                                  const affine_mem* __restrict__ pts, const affine_mem* __restrict__ gens, fq* __restrict__ chal,
+                                                  int* __restrict__ bad) {
+    __shared__ __align__(4) uint8_t lds[64 * MSG_STRIDE];
+    size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (gid >= nproofs * 4) return;
+    size_t pr = gid >> 2;
+    int job = (int)(gid & 3);
+    if (bad[pr]) return;
+    uint8_t* buf = lds + threadIdx.x * MSG_STRIDE;
+    const int NPT = 4 + 2 * k + m;
+    const affine_mem* P = pts + pr * NPT;
+    const uint8_t* pf = proofs + pr * proof_len;
+    int pos = 0;
+    if (job == 0) {  // y = H(A, S)                                     range_proof.rs:565-567
+        msg_put_point(buf, pos, P[0]);
+        msg_put_point(buf, pos, P[1]);
+    } else if (job == 1) {  // x = H(T1, T2, G, H)                      :576-578
+        msg_put_point(buf, pos, P[2]);
+        msg_put_point(buf, pos, P[3]);
+        msg_put_point(buf, pos, gens[2 * nm]);
+        msg_put_point(buf, pos, gens[2 * nm + 1]);
+    } else if (job == 2) {  // x_u = H(tau_x, miu, tx)                  :581-585
+        const uint8_t* sc = pf + PF_SCALARS;
+        const uint8_t* ab = pf + PF_AB(k);
+        // scalars in the proof must be canonical (< q), as curv's deserialisation yields
+        bool okc = fq_be_is_canonical(sc) && fq_be_is_canonical(sc + 32) && fq_be_is_canonical(sc + 64) && fq_be_is_canonical(ab) &&
+                   fq_be_is_canonical(ab + 32);
+        if (!okc) atomicOr(&bad[pr], 1);
+        msg_put_bigint32(buf, pos, sc);
+        msg_put_bigint32(buf, pos, sc + 32);
+        msg_put_bigint32(buf, pos, sc + 64);
+    } else {  // c = H(A, S, T1, T2, G, H)                              :591-593
+        msg_put_point(buf, pos, P[0]);
+        msg_put_point(buf, pos, P[1]);
+        msg_put_point(buf, pos, P[2]);
+        msg_put_point(buf, pos, P[3]);
+        msg_put_point(buf, pos, gens[2 * nm]);
+        msg_put_point(buf, pos, gens[2 * nm + 1]);
+    }
+    chal[pr * CH_COUNT(k) + job] = msg_result_scalar(buf, pos);
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int window_digit(const fq& kk, int c, int w, uint32_t& carry) {
+    const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
+    int bit = w * c;
+    uint32_t v = 0;
+    if (bit < 256) {
+        int limb = bit >> 5, sh = bit & 31;
+        uint64_t two = kk.v[limb];
+        if (limb + 1 < 8) two |= (uint64_t)kk.v[limb + 1] << 32;
+        v = (uint32_t)(two >> sh) & mask;
+    }
+    v += carry;
+    if (v > half) {
+        carry = 1;
+        return (int)v - (int)(1u << c);
+    }
+    carry = 0;
+    return (int)v;
+}
+
+__device__ __forceinline__ void store_digits(const fq& kk, int c, int W, int16_t* __restrict__ out) {
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) out[w] = (int16_t)window_digit(kk, c, w, carry);
+}
+
+// y*G (lanes 0-7) and x_u*G (lanes 8-15) per proof: table gathers + mixed adds, 8-lane tree sum.
+__global__ __launch_bounds__(256) void k_bpv_fixmul(int k, int nm, size_t nproofs, const affine_mem* __restrict__ table, int c, int W,
+                                                    const fq* __restrict__ chal, xyzz* __restrict__ fixres, const int* __restrict__ bad) {
+    __shared__ xyzz red[256];
+    const int tid = threadIdx.x, lane = tid & 15, sub = lane & 7, which = lane >> 3;
+    const size_t pr = (size_t)blockIdx.x * 16 + (tid >> 4);
+    const int NB = 1 << (c - 1);
+    xyzz acc = xyzz_inf();
+    if (pr < nproofs && !bad[pr]) {
+        fq s = chal[pr * CH_COUNT(k) + (which ? CH_XU : CH_Y)];
+        const size_t pG = (size_t)2 * nm;
+        uint32_t carry = 0;
+        for (int w = 0; w < W; w++) {
+            int d = window_digit(s, c, w, carry);
+            if ((w & 7) == sub && d != 0) {
+                affine e = affine_load(table[(pG * W + w) * NB + ((d < 0 ? -d : d) - 1)]);
+                if (d < 0) e.y = fp_neg(e.y);
+                xyzz_madd(acc, e);
+            }
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int off = 4; off >= 1; off >>= 1) {
+        if (sub < off) {
+            xyzz v = red[tid];
+            xyzz o = red[tid + off];
+            xyzz_add(v, o);
+            red[tid] = v;
+        }
+        __syncthreads();
+    }
+    if (sub == 0 && pr < nproofs) fixres[pr * 2 + which] = red[tid];
+}
+
+// affine yG, ux with ONE inversion (Montgomery's trick on the two ZZZ).  y = 0 or x_u = 0 makes a
+// result the identity: the reference would panic (:569 mod_inv unwrap) / cannot hash it -> malformed.
+__global__ __launch_bounds__(64) void k_bpv_fixinv(size_t nproofs, const xyzz* __restrict__ fixres, affine_mem* __restrict__ fixaff,
+                                                   int* __restrict__ bad) {
+    size_t pr = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (pr >= nproofs || bad[pr]) return;
+    xyzz a = fixres[pr * 2], b = fixres[pr * 2 + 1];
+    if (xyzz_is_inf(a) || xyzz_is_inf(b)) {
+        atomicOr(&bad[pr], 1);
+        return;
+    }
+    fp inv = fp_inv(fp_mul(a.ZZZ, b.ZZZ));
+    fp ia = fp_mul(inv, b.ZZZ), ib = fp_mul(inv, a.ZZZ);
+    affine r;
+    fp zi = fp_mul(a.ZZ, ia);
+    r.x = fp_mul(a.X, fp_sqr(zi));
+    r.y = fp_mul(a.Y, ia);
+    fixaff[pr * 2] = affine_store(r);
+    zi = fp_mul(b.ZZ, ib);
+    r.x = fp_mul(b.X, fp_sqr(zi));
+    r.y = fp_mul(b.Y, ib);
+    fixaff[pr * 2 + 1] = affine_store(r);
+}
+
+// z = H(yG) (job 0) and x_j = H(L_j, R_j, ux) (job 1 + j)
+__global__ __launch_bounds__(64) void k_bpv_hash2(int k, int m, size_t nproofs, const affine_mem* __restrict__ pts,
+                                                  const affine_mem* __restrict__ fixaff, fq* __restrict__ chal, const int* __restrict__ bad) {
+    __shared__ __align__(4) uint8_t lds[64 * MSG_STRIDE];
+    size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const int jobs = k + 1;
+    if (gid >= nproofs * jobs) return;
+    size_t pr = gid / jobs;
+    int job = (int)(gid % jobs);
+    if (bad[pr]) return;
+    uint8_t* buf = lds + threadIdx.x * MSG_STRIDE;
+    const int NPT = 4 + 2 * k + m;
+    const affine_mem* P = pts + pr * NPT;
+    int pos = 0;
+    if (job == 0) {
+        msg_put_point(buf, pos, fixaff[pr * 2]);
+        chal[pr * CH_COUNT(k) + CH_Z] = msg_result_scalar(buf, pos);
+    } else {
+        int j = job - 1;
+        msg_put_point(buf, pos, P[4 + j]);
+        msg_put_point(buf, pos, P[4 + k + j]);
+        msg_put_point(buf, pos, fixaff[pr * 2 + 1]);
+        chal[pr * CH_COUNT(k) + CH_XJ + j] = msg_result_scalar(buf, pos);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-proof constants for k_bpv_vec (Montgomery domain)
+#define CS_Z 0
+#define CS_A 1
+#define CS_B 2
+#define CS_XJ 3                        // k : x_j
+#define CS_XINV(k) (3 + (k))           // k : x_j^-1
+#define CS_YINVP(k) (3 + 2 * (k))      // k : y^-(2^t)
+#define CS_ZPOW(k) (3 + 3 * (k))       // m : z^(2+j)
+#define CS_COUNT(k, m) (3 + 3 * (k) + (m))
+#define BPV_MAXK 16
+
+__global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
+                                                   const fq* __restrict__ chal, int c, int W, int16_t* __restrict__ digF, fq* __restrict__ varS,
+                                                   fq* __restrict__ cst, int* __restrict__ bad) {
+    size_t pr = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (pr >= nproofs || bad[pr]) return;
+    const int nm = n_bits * m;
+    const int NV = 3 + 2 * k + m;
+    const uint8_t* pf = proofs + pr * proof_len;
+    const uint8_t* sc = pf + PF_SCALARS;
+    const uint8_t* ab = pf + PF_AB(k);
+    const fq* ch = chal + pr * CH_COUNT(k);
+    fq* cs = cst + pr * CS_COUNT(k, m);
+    fq* vs = varS + pr * (size_t)NV;
+    const fq ONE = fq_mont_one();
+
+    fq y = ch[CH_Y];
+    fq y_m = fq_to_mont(y), z_m = fq_to_mont(ch[CH_Z]), x_m = fq_to_mont(ch[CH_X]), xu_m = fq_to_mont(ch[CH_XU]), c_m = fq_to_mont(ch[CH_C]);
+    fq taux_m = fq_to_mont(fq_from_be_reduce(sc)), miu_m = fq_to_mont(fq_from_be_reduce(sc + 32)), tx_m = fq_to_mont(fq_from_be_reduce(sc + 64));
+    fq a_m = fq_to_mont(fq_from_be_reduce(ab)), b_m = fq_to_mont(fq_from_be_reduce(ab + 32));
+
+    // batched inversion of (y, y - 1, x_0 .. x_{k-1}); a zero x_j / y is `.invert().unwrap()` panicking (:658, :569)
+    fq ym1 = fq_sub(y_m, ONE);
+    const bool y_is_one = fq_is_zero(ym1);
+    if (y_is_one) ym1 = ONE;
+    fq pref[BPV_MAXK + 2];
+    fq run = y_m;
+    pref[0] = run;
+    run = fq_mont_mul(run, ym1);
+    pref[1] = run;
+    bool zero_ch = fq_is_zero(y);
+    for (int j = 0; j < k; j++) {
+        fq xv = ch[CH_XJ + j];
+        zero_ch = zero_ch || fq_is_zero(xv);
+        fq xm = fq_to_mont(xv);
+        cs[CS_XJ + j] = xm;
+        run = fq_mont_mul(run, xm);
+        pref[2 + j] = run;
+    }
+    if (zero_ch) {
+        atomicOr(&bad[pr], 1);
+        return;
+    }
+    fq inv = fq_mont_inv(run);
+    for (int j = k - 1; j >= 0; j--) {
+        fq xm = cs[CS_XJ + j];
+        fq xi = fq_mont_mul(inv, pref[1 + j]);
+        inv = fq_mont_mul(inv, xm);
+        cs[CS_XINV(k) + j] = xi;
+        vs[1 + j] = fq_from_mont(fq_neg(fq_mont_mul(xm, xm)));      // L_j : -x_j^2     :665, 730
+        vs[1 + k + j] = fq_from_mont(fq_neg(fq_mont_mul(xi, xi)));  // R_j : -x_j^-2    :666, 731
+    }
+    fq ym1inv = fq_mont_mul(inv, pref[0]);
+    fq yinv_m = fq_mont_mul(inv, ym1);
+    // y^-(2^t), y^nm
+    fq yp = yinv_m, ynm = y_m;
+    for (int t = 0; t < k; t++) {
+        cs[CS_YINVP(k) + t] = yp;
+        yp = fq_mont_mul(yp, yp);
+        ynm = fq_mont_mul(ynm, ynm);
+    }
+    // sum_{i<nm} y^i = (y^nm - 1)/(y - 1)   (nm if y == 1)                    :606-609
+    fq sum_y;
+    if (y_is_one) {
+        fq t = fq_zero();
+        t.v[0] = (uint32_t)nm;
+        sum_y = fq_to_mont(t);
+    } else {
+        sum_y = fq_mont_mul(fq_sub(ynm, ONE), ym1inv);
+    }
+    // z^(2+j); sum_d = (2^n - 1) sum_j z^(2+j)                                 :597-599, 621-636
+    fq zsq = fq_mont_mul(z_m, z_m);
+    fq zp = zsq, sum_z = fq_zero();
+    for (int j = 0; j < m; j++) {
+        cs[CS_ZPOW(k) + j] = zp;
+        sum_z = fq_add(sum_z, zp);
+        vs[1 + 2 * k + j] = fq_from_mont(fq_mont_mul(c_m, zp));    // V_j : c z^(2+j)  :734-736
+        zp = fq_mont_mul(zp, z_m);
+    }
+    fq two_n = fq_zero();  // 2^n - 1 as a plain integer (n_bits <= 64 in every config; general for < 256)
+    for (int b = 0; b < n_bits; b++) two_n.v[b >> 5] |= 1u << (b & 31);
+    fq sum_d = fq_mont_mul(fq_to_mont(two_n), sum_z);
+    // delta = (z - z^2) sum_y - z sum_d                                        :639-642
+    fq delta = fq_sub(fq_mont_mul(fq_sub(z_m, zsq), sum_y), fq_mont_mul(sum_d, z_m));
+    // G : x_u (ab - tx) + c (delta - tx) ; H : miu - c tau_x                   :708-723
+    fq abm = fq_mont_mul(a_m, b_m);
+    fq sG = fq_add(fq_mont_mul(xu_m, fq_sub(abm, tx_m)), fq_mont_mul(c_m, fq_sub(delta, tx_m)));
+    fq sH = fq_sub(miu_m, fq_mont_mul(c_m, taux_m));
+    int16_t* dg = digF + pr * (size_t)(2 * nm + 2) * W;
+    store_digits(fq_from_mont(sG), c, W, dg + (size_t)(2 * nm) * W);
+    store_digits(fq_from_mont(sH), c, W, dg + (size_t)(2 * nm + 1) * W);
+    // S : -x ; T1 : c x ; T2 : c x^2                                           :727, 739-740
+    vs[0] = fq_from_mont(fq_neg(x_m));
+    fq cx = fq_mont_mul(c_m, x_m);
+    vs[1 + 2 * k + m] = fq_from_mont(cx);
+    vs[2 + 2 * k + m] = fq_from_mont(fq_mont_mul(cx, x_m));
+    cs[CS_Z] = z_m;
+    cs[CS_A] = a_m;
+    cs[CS_B] = b_m;
+}
+
+// One lane per (proof, i): g_i : a s_i + z ; h_i : y^-i (b s_i^-1 - d_i) - z          :670-705
+// s_i = prod_t (bit_t(i) ? x_{k-1-t} : x_{k-1-t}^-1), s_i^-1 = s_{nm-1-i}; d_i = z^(2+i/n) 2^(i mod n).
+__global__ __launch_bounds__(256) void k_bpv_vec(int n_bits, int m, int k, size_t nproofs, const fq* __restrict__ cst, int c, int W,
+                                                 int16_t* __restrict__ digF, const int* __restrict__ bad) {
+    const int nm = n_bits * m;
+    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= nproofs * (size_t)nm) return;
+    size_t pr = gid / nm;
+    int i = (int)(gid % nm);
+    if (bad[pr]) return;
+    const fq* cs = cst + pr * CS_COUNT(k, m);
+    fq s = fq_mont_one(), sinv = s, yip = s;
+    for (int t = 0; t < k; t++) {
+        fq xm = cs[CS_XJ + (k - 1 - t)], xi = cs[CS_XINV(k) + (k - 1 - t)];
+        if ((i >> t) & 1) {
+            s = fq_mont_mul(s, xm);
+            sinv = fq_mont_mul(sinv, xi);
+            yip = fq_mont_mul(yip, cs[CS_YINVP(k) + t]);
+        } else {
+            s = fq_mont_mul(s, xi);
+            sinv = fq_mont_mul(sinv, xm);
+        }
+    }
+    fq z_m = cs[CS_Z];
+    fq gs = fq_add(fq_mont_mul(cs[CS_A], s), z_m);
+    fq two_r = fq_zero();
+    int r = i % n_bits;
+    two_r.v[r >> 5] = 1u << (r & 31);
+    fq d_i = fq_mont_mul(fq_to_mont(two_r), cs[CS_ZPOW(k) + i / n_bits]);
+    fq hs = fq_sub(fq_mont_mul(yip, fq_sub(fq_mont_mul(cs[CS_B], sinv), d_i)), z_m);
+    int16_t* dg = digF + pr * (size_t)(2 * nm + 2) * W;
+    store_digits(fq_from_mont(gs), c, W, dg + (size_t)i * W);
+    store_digits(fq_from_mont(hs), c, W, dg + (size_t)(nm + i) * W);
+}
+
+// ------------------------------------------------------------------------------------------------
+size_t bpv_chal_count(int k) { return CH_COUNT(k); }
+size_t bpv_cst_count(int k, int m) { return CS_COUNT(k, m); }
+
+hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
+                                      const affine_mem* gens, const affine_mem* table, int c, int W, int16_t* digF, fq* varS, fq* chal,
+                                      fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st) {
+    const int nm = n_bits * m;
+    hipLaunchKernelGGL(k_bpv_hash1, dim3((unsigned)((nproofs * 4 + 63) / 64)), dim3(64), 0, st, proofs, proof_len, k, m, nm, nproofs, pts, gens,
+                       chal, bad);
+    hipLaunchKernelGGL(k_bpv_fixmul, dim3((unsigned)((nproofs + 15) / 16)), dim3(256), 0, st, k, nm, nproofs, table, c, W, chal, fixres, bad);
+    hipLaunchKernelGGL(k_bpv_fixinv, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, nproofs, fixres, fixaff, bad);
+    hipLaunchKernelGGL(k_bpv_hash2, dim3((unsigned)((nproofs * (k + 1) + 63) / 64)), dim3(64), 0, st, k, m, nproofs, pts, fixaff, chal, bad);
+    hipLaunchKernelGGL(k_bpv_consts, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W,
+                       digF, varS, cst, bad);
+    hipLaunchKernelGGL(k_bpv_vec, dim3((unsigned)((nproofs * (size_t)nm + 255) / 256)), dim3(256), 0, st, n_bits, m, k, nproofs, cst, c, W, digF,
+                       bad);
+    return hipGetLastError();
+}
+
+}  // namespace bp
