@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per proof in k_bpv_msm (16/32/64)")
     ap.add_argument("--window-bits", type=int, default=0, help="fixed-base table window (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-check", action="store_true", help="timing experiments only: do not compare verdicts")
     ap.add_argument("--cpu-sample", type=int, default=96, help="proofs verified by the CPU baseline")
     return ap.parse_args()
 
@@ -137,7 +138,7 @@ def main():
         step()
     ctx.sync()
     got = bytes(d_verdicts.cpu().numpy().tobytes())
-    if got != bytes(want):
+    if got != bytes(want) and not args.skip_check:
         raise SystemExit("verdict mismatch on rank %d" % rank)
 
     def barrier():

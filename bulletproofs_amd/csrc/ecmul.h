@@ -1,0 +1,82 @@
+// Variable-base scalar multiplication k * P for one point per lane (host + device).
+//
+// Used for the proof-specific terms of the verifier MSM (S, L_j, R_j, V_j, T1, T2 with 256-bit
+// scalars: /root/reference/src/proofs/range_proof.rs:727-774), which cannot come from a table.
+//   * GLV: k = k1 + k2*lambda with |k1|,|k2| < 2^129 and lambda*(x,y) = (beta*x, y), so one chain of
+//     128 doublings serves both halves (instead of 256);
+//   * fixed 4-bit signed windows, multiples 1P..8P kept as XYZZ in a caller-provided 8-entry slice
+//     (lane-private global scratch on the GPU);
+//   * uniform control flow: every lane does 4 doublings + 2 additions per window, so a wavefront
+//     never serialises on "+P / -P / nothing" branches as a NAF ladder would.
+#pragma once
+#include "ec.h"
+#include "fq.h"
+
+namespace bp {
+
+#define ECMUL_NT 8      // table entries per point
+#define ECMUL_WINS 33   // 4-bit windows covering 129-bit magnitudes plus the signed-digit carry
+
+BP_HD fp fp_beta() {
+    fp b = {{0x119501eeu, 0x09cb6143u, 0x1d626570u, 0x0092ea25u, 0x034e99cfu, 0x03cf561au, 0x1c41b991u, 0x056caf80u, 0x007ae96au}};
+    return b;
+}
+
+// carry-in bit per window for the signed recoding of a < 2^129 magnitude (digit = nibble + carry_in,
+// minus 16 and carry out if > 8)
+BP_HD uint64_t ecmul_carry_mask(const fq& k) {
+    uint64_t mask = 0;
+    uint32_t carry = 0;
+    for (int w = 0; w < ECMUL_WINS - 1; w++) {
+        uint32_t v = ((k.v[w >> 3] >> ((w & 7) * 4)) & 15u) + carry;
+        carry = v > 8u ? 1u : 0u;
+        mask |= (uint64_t)carry << (w + 1);
+    }
+    return mask;
+}
+BP_HD int ecmul_digit(const fq& k, uint64_t cmask, int w) {
+    uint32_t v = ((k.v[w >> 3] >> ((w & 7) * 4)) & 15u) + (uint32_t)((cmask >> w) & 1u);
+    return v > 8u ? (int)v - 16 : (int)v;
+}
+
+BP_HD xyzz ec_mul_glv(const affine& P, const fq& k, xyzz* tab) {
+    if (affine_is_inf(P)) return xyzz_inf();
+    fq k1, k2;
+    bool n1, n2;
+    fq_glv_split(k, k1, n1, k2, n2);
+    xyzz t = xyzz_from_affine(P);
+    tab[0] = t;
+    t = xyzz_dbl_affine(P);
+    tab[1] = t;
+    for (int i = 2; i < ECMUL_NT; i++) {
+        xyzz_madd(t, P);
+        tab[i] = t;
+    }
+    const uint64_t c1 = ecmul_carry_mask(k1), c2 = ecmul_carry_mask(k2);
+    const fp beta = fp_beta();
+    xyzz acc = xyzz_inf();
+    for (int w = ECMUL_WINS - 1; w >= 0; w--) {
+        if (w != ECMUL_WINS - 1) {
+            acc = xyzz_dbl(acc);
+            acc = xyzz_dbl(acc);
+            acc = xyzz_dbl(acc);
+            acc = xyzz_dbl(acc);
+        }
+        int d1 = ecmul_digit(k1, c1, w);
+        if (d1 != 0) {
+            xyzz e = tab[(d1 < 0 ? -d1 : d1) - 1];
+            if ((d1 < 0) != n1) e.Y = fp_neg(e.Y);
+            xyzz_add(acc, e);
+        }
+        int d2 = ecmul_digit(k2, c2, w);
+        if (d2 != 0) {
+            xyzz e = tab[(d2 < 0 ? -d2 : d2) - 1];
+            e.X = fp_mul(e.X, beta);
+            if ((d2 < 0) != n2) e.Y = fp_neg(e.Y);
+            xyzz_add(acc, e);
+        }
+    }
+    return acc;
+}
+
+}  // namespace bp

@@ -166,6 +166,70 @@ BP_HD_NOINLINE fq fq_mont_inv(fq a) {
 }
 BP_HD fq fq_inv(const fq& a) { return fq_from_mont(fq_mont_inv(fq_to_mont(a))); }
 
+// ---- GLV endomorphism split (secp256k1: lambda^3 = 1 mod q, phi(x, y) = (beta x, y) = lambda * (x, y)) ----
+// k = k1 + k2 * lambda (mod q) with |k1|, |k2| < 2^128 (constants and method of libsecp256k1's
+// scalar_split_lambda).  Halves the doubling chain of every variable-base multiplication.
+// ((k * g + 2^383) >> 384), k and g 256-bit: the rounded quotient used for c1, c2 (< 2^128).
+BP_HD fq fq_mul_shift384(const fq& k, const uint32_t g[8]) {
+    uint32_t t[16];
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        c += (uint64_t)k.v[0] * g[j];
+        t[j] = (uint32_t)c;
+        c >>= 32;
+    }
+    t[8] = (uint32_t)c;
+#pragma unroll
+    for (int i = 1; i < 8; i++) {
+        c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (uint64_t)k.v[i] * g[j] + t[i + j];
+            t[i + j] = (uint32_t)c;
+            c >>= 32;
+        }
+        t[i + 8] = (uint32_t)c;
+    }
+    // + 2^383 = bit 31 of limb 11, then take limbs 12..15
+    c = (uint64_t)t[11] + 0x80000000u;
+    c >>= 32;
+    fq r = fq_zero();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        c += t[12 + i];
+        r.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return r;
+}
+// k (plain, < q) -> magnitudes k1, k2 (< 2^129, plain) and their signs (true = negative).
+BP_HD void fq_glv_split(const fq& k, fq& k1, bool& neg1, fq& k2, bool& neg2) {
+    const uint32_t G1[8] = {0x45dbb031u, 0xe893209au, 0x71e8ca7fu, 0x3daa8a14u, 0x9284eb15u, 0xe86c90e4u, 0xa7d46bcdu, 0x3086d221u};
+    const uint32_t G2[8] = {0x8ac47f71u, 0x1571b4aeu, 0x9df506c6u, 0x221208acu, 0x0abfe4c4u, 0x6f547fa9u, 0x010e8828u, 0xe4437ed6u};
+    const fq MB1_M = {{0x0ad9263cu, 0xc50468d0u, 0xfaa6ed42u, 0x1b1c8205u, 0x8ac47f71u, 0x1571b4aeu, 0x9df506c6u, 0x221208acu}};
+    const fq MB2_M = {{0x6a144696u, 0x0cac5e50u, 0xf3ba5939u, 0x1e8a8dc5u, 0xba244fceu, 0x176cdf65u, 0x8e173580u, 0xc25575ebu}};
+    const fq LAM_M = {{0xc9926c9eu, 0xf07deb3du, 0x83c6944cu, 0x2c93e7adu, 0x52697d91u, 0x73a96606u, 0x8558d639u, 0x53284017u}};
+    const uint32_t HALF_Q[8] = {0x681b20a0u, 0xdfe92f46u, 0x57a4501du, 0x5d576e73u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu};
+    fq c1 = fq_mul_shift384(k, G1), c2 = fq_mul_shift384(k, G2);
+    fq r2 = fq_add(fq_mont_mul(c1, MB1_M), fq_mont_mul(c2, MB2_M));  // mont_mul(a, b*R) = a*b
+    fq r1 = fq_sub(k, fq_mont_mul(r2, LAM_M));
+    // r > q/2  <=>  HALF_Q - r borrows
+    auto gt_half = [&](const fq& r) {
+        int64_t b = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            b += (int64_t)HALF_Q[i] - (int64_t)r.v[i];
+            b >>= 32;
+        }
+        return b != 0;
+    };
+    neg1 = gt_half(r1);
+    neg2 = gt_half(r2);
+    k1 = neg1 ? fq_neg(r1) : r1;
+    k2 = neg2 ? fq_neg(r2) : r2;
+}
+
 // 32 big-endian bytes -> scalar reduced mod q (`Scalar::from(&BigInt)` for 256-bit inputs).
 BP_HD fq fq_from_be_reduce(const uint8_t* b) {
     fq r;

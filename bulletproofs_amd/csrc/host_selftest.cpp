@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "ec.h"
+#include "ecmul.h"
 #include "fq.h"
 #include "sha256.h"
 
@@ -23,6 +24,15 @@ void bpt_fq_mul(uint8_t* out, const uint8_t* a, const uint8_t* b) { fq_to_be(out
 void bpt_fq_add(uint8_t* out, const uint8_t* a, const uint8_t* b) { fq_to_be(out, fq_add(fq_from_be_raw(a), fq_from_be_raw(b))); }
 void bpt_fq_sub(uint8_t* out, const uint8_t* a, const uint8_t* b) { fq_to_be(out, fq_sub(fq_from_be_raw(a), fq_from_be_raw(b))); }
 void bpt_fq_inv(uint8_t* out, const uint8_t* a) { fq_to_be(out, fq_inv(fq_from_be_raw(a))); }
+// GLV split: k1, k2 magnitudes (32 B BE each) and sign flags (bit 0: k1 negative, bit 1: k2 negative)
+int bpt_fq_glv(uint8_t* k1, uint8_t* k2, const uint8_t* k) {
+    fq a, b;
+    bool n1, n2;
+    fq_glv_split(fq_from_be_raw(k), a, n1, b, n2);
+    fq_to_be(k1, a);
+    fq_to_be(k2, b);
+    return (n1 ? 1 : 0) | (n2 ? 2 : 0);
+}
 void bpt_fq_reduce(uint8_t* out, const uint8_t* a) { fq_to_be(out, fq_from_be_raw(a)); }
 
 // out = a + b through XYZZ (mixed add), normalised
@@ -48,6 +58,12 @@ void bpt_ec_mul(uint8_t* out, const uint8_t* a, const uint8_t* k) {
         if ((k[i / 8] >> (7 - (i % 8))) & 1) xyzz_madd(acc, p);
     }
     affine_to_be64(out, xyzz_to_affine(acc));
+}
+// out = k * a through the GLV fixed-window ladder of ecmul.h, normalised
+void bpt_ec_mul_glv(uint8_t* out, const uint8_t* a, const uint8_t* k) {
+    xyzz tab[ECMUL_NT];
+    xyzz r = ec_mul_glv(affine_from_be64(a), fq_from_be_reduce(k), tab);
+    affine_to_be64(out, xyzz_to_affine(r));
 }
 int bpt_ec_decompress(uint8_t* out, const uint8_t* in33) {
     affine p;

@@ -15,8 +15,10 @@
 // Per-proof verdicts follow `Result<(), Errors>`: 0 = Ok, 3 = RangeProofError, 255 = the proof bytes
 // would not deserialize in the reference (bad point / scalar >= q / zero challenge).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "ec.h"
+#include "ecmul.h"
 #include "fq.h"
 #include "kernels.h"
 
@@ -54,60 +56,16 @@ __global__ void k_bpv_decompress(const uint8_t* __restrict__ proofs, size_t proo
 }
 
 // ------------------------------------------------------------------------------------------------
-// k * P for one variable point: fixed 4-bit signed windows (digits in [-8, 8], 65 windows), with the
-// multiples 1P..8P kept as XYZZ in a lane-private slice of a global scratch buffer.  Control flow is
-// uniform across the wave (4 doublings + 1 addition per window for every lane): a NAF
-// double-and-add would make every lane wait on both the +P and the -P branch at almost every bit.
-#define VAR_WBITS 4
-#define VAR_NT 8  // table entries
-__device__ __forceinline__ xyzz window_mul(const affine& P, const fq& k, xyzz* __restrict__ tab) {
-    if (affine_is_inf(P)) return xyzz_inf();
-    xyzz t = xyzz_from_affine(P);
-    tab[0] = t;
-    t = xyzz_dbl_affine(P);
-    tab[1] = t;
-    for (int i = 2; i < VAR_NT; i++) {
-        xyzz_madd(t, P);
-        tab[i] = t;
-    }
-    // signed digits, most significant window first; recode on the fly from the top:
-    // d_w = bits(w) + carry_in(w) - 16*carry_out(w) needs the carries from below, so precompute them.
-    // carry into window w+1 is 1 iff (bits(w) + carry(w)) > 8.
-    uint32_t cmask[3] = {0, 0, 0};  // carry-in bit per window (65 windows)
-    {
-        uint32_t carry = 0;
-        for (int w = 0; w < 64; w++) {
-            uint32_t v = ((k.v[w >> 3] >> ((w & 7) * 4)) & 15u) + carry;
-            carry = v > 8u ? 1u : 0u;
-            if (carry) cmask[(w + 1) >> 5] |= 1u << ((w + 1) & 31);
-        }
-    }
-    xyzz acc = xyzz_inf();
-    for (int w = 64; w >= 0; w--) {
-        if (w != 64) {
-            acc = xyzz_dbl(acc);
-            acc = xyzz_dbl(acc);
-            acc = xyzz_dbl(acc);
-            acc = xyzz_dbl(acc);
-        }
-        uint32_t bits = (w < 64) ? ((k.v[w >> 3] >> ((w & 7) * 4)) & 15u) : 0u;
-        uint32_t v = bits + ((cmask[w >> 5] >> (w & 31)) & 1u);
-        int d = v > 8u ? (int)v - 16 : (int)v;
-        if (d != 0) {
-            xyzz e = tab[(d < 0 ? -d : d) - 1];
-            if (d < 0) e.Y = fp_neg(e.Y);
-            xyzz_add(acc, e);
-        }
-    }
-    return acc;
-}
+#ifndef BPV_MSM_WAVES
+#define BPV_MSM_WAVES 2
+#endif
 
 // TP lanes per proof; 256-thread workgroups.
 template <int TP>
-__global__ __launch_bounds__(256) void k_bpv_msm(int n_bits, int m, int k, size_t nproofs, const affine_mem* __restrict__ pts,
+__global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int m, int k, size_t nproofs, const affine_mem* __restrict__ pts,
                                                  const affine_mem* __restrict__ table, int c, int W, const int16_t* __restrict__ digF,
                                                  const fq* __restrict__ varS, xyzz* __restrict__ vartab, const int* __restrict__ bad,
-                                                 uint8_t* __restrict__ verdicts) {
+                                                 uint8_t* __restrict__ verdicts, int dbg_skip) {
     __shared__ xyzz red[256];
     const int tid = threadIdx.x;
     const int lane = tid % TP;
@@ -121,7 +79,7 @@ __global__ __launch_bounds__(256) void k_bpv_msm(int n_bits, int m, int k, size_
     if (active) {
         const int nfw = (2 * nm + 2) * W;
         const int16_t* dg = digF + pr * (size_t)nfw;
-        for (int idx = lane; idx < nfw; idx += TP) {
+        for (int idx = lane; idx < ((dbg_skip & 1) ? 0 : nfw); idx += TP) {
             int d = dg[idx];
             if (d != 0) {
                 affine e = affine_load(table[(size_t)idx * NB + ((d < 0 ? -d : d) - 1)]);
@@ -131,10 +89,10 @@ __global__ __launch_bounds__(256) void k_bpv_msm(int n_bits, int m, int k, size_
         }
         const affine_mem* P = pts + pr * NPT;
         const fq* vs = varS + pr * (size_t)NV;
-        for (int v = lane; v < NV; v += TP) {
+        for (int v = lane; v < ((dbg_skip & 2) ? 0 : NV); v += TP) {
             // variable point order: S, L_0.., R_0.., V_0.., T1, T2  ->  index into pts
             int pi = (v == 0) ? 1 : (v < 1 + 2 * k + m) ? (3 + v) : (v == 1 + 2 * k + m ? 2 : 3);
-            xyzz t = window_mul(affine_load(P[pi]), vs[v], vartab + ((size_t)blockIdx.x * 256 + tid) * VAR_NT);
+            xyzz t = ec_mul_glv(affine_load(P[pi]), vs[v], vartab + ((size_t)blockIdx.x * 256 + tid) * ECMUL_NT);
             xyzz_add(acc, t);
         }
     }
@@ -173,17 +131,19 @@ hipError_t launch_bpv_decompress(const uint8_t* proofs, size_t proof_len, const 
 }
 size_t bpv_msm_vartab_bytes(int tp, size_t nproofs) {
     size_t blocks = (nproofs + (256 / tp) - 1) / (256 / tp);
-    return blocks * 256 * VAR_NT * sizeof(xyzz);
+    return blocks * 256 * ECMUL_NT * sizeof(xyzz);
 }
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
                           const int16_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st) {
     unsigned blocks = (unsigned)((nproofs + (256 / tp) - 1) / (256 / tp));
+    const char* e = getenv("BP_DEBUG_SKIP");  // timing experiments only: 1 = skip fixed part, 2 = skip variable part
+    int dbg = e ? atoi(e) : 0;
     if (tp == 16)
-        hipLaunchKernelGGL(k_bpv_msm<16>, dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, bad, verdicts);
+        hipLaunchKernelGGL(k_bpv_msm<16>, dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, bad, verdicts, dbg);
     else if (tp == 32)
-        hipLaunchKernelGGL(k_bpv_msm<32>, dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, bad, verdicts);
+        hipLaunchKernelGGL(k_bpv_msm<32>, dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, bad, verdicts, dbg);
     else
-        hipLaunchKernelGGL(k_bpv_msm<64>, dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, bad, verdicts);
+        hipLaunchKernelGGL(k_bpv_msm<64>, dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, bad, verdicts, dbg);
     return hipGetLastError();
 }
 
