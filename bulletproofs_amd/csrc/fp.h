@@ -26,9 +26,10 @@
 #include <hip/hip_runtime.h>
 #define BP_HD __host__ __device__ __forceinline__
 #define BP_HD_NOINLINE inline __host__ __device__ __noinline__
-// fp_mul / fp_sqr are a few hundred VALU instructions each; a point addition uses 10-14 of them.
-// Calling them as real functions keeps kernels inside the instruction cache (override to measure).
-#ifndef BP_FP_MUL_INLINE
+// fp_mul / fp_sqr are ~200 VALU instructions each.  Inlined they avoid ~30 argument moves and the
+// call sequence per multiply (measured with bench_micro/ecops: xyzz_madd 5.5 us -> 4.0 us per wave);
+// -DBP_FP_MUL_NOINLINE keeps them as real functions (smaller code, for experiments).
+#ifdef BP_FP_MUL_NOINLINE
 #define BP_HD_MUL inline __host__ __device__ __noinline__
 #else
 #define BP_HD_MUL __host__ __device__ __forceinline__
@@ -37,6 +38,14 @@
 #define BP_HD inline
 #define BP_HD_NOINLINE inline
 #define BP_HD_MUL inline
+#endif
+
+// Optimisation barrier on a 32-bit value (device only): stops value-range facts from flowing into
+// the multiplier when fp_mul is inlined (see DESIGN.md "inlined field multiply").
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BP_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define BP_OPAQUE(x) ((void)0)
 #endif
 
 namespace bp {
@@ -168,6 +177,11 @@ BP_HD fp fp_fold18(const uint32_t r[18]) {
 
 // 9x9 product scanning: each column is one 64-bit accumulator fed by v_mad_u64_u32; 81 MADs.
 BP_HD_MUL fp fp_mul(fp a, fp b) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        BP_OPAQUE(a.v[i]);
+        BP_OPAQUE(b.v[i]);
+    }
     uint32_t r[18];
     uint64_t c = 0;
 #pragma unroll
@@ -183,6 +197,8 @@ BP_HD_MUL fp fp_mul(fp a, fp b) {
 
 // Squaring: 45 MADs (off-diagonal terms use a doubled operand).
 BP_HD_MUL fp fp_sqr(fp a) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) BP_OPAQUE(a.v[i]);
     uint32_t d[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
