@@ -8,6 +8,8 @@ from ._lib import (  # noqa: F401
     BpError,
     Context,
     Gens,
+    generate_bases,
+    KZEN_SEED,
     lib,
     lib_path,
     EXPORTED_SYMBOLS,

@@ -24,6 +24,14 @@ EXPORTED_SYMBOLS = [
     "bp_rangeproof_verify_batch_device",
     "bp_ctx_sync",
     "bp_verify_set_lanes",
+    "bp_scalar_mul_batch",
+    "bp_fold_bases",
+    "bp_fixed_base_mul_batch",
+    "bp_generate_bases",
+    "bp_rangeproof_prove",
+    "bp_rangeproof_verify",
+    "bp_wip_rangeproof_prove",
+    "bp_wip_rangeproof_verify",
     "bp_profile_enable",
     "bp_profile_reset",
     "bp_profile_get",
@@ -81,6 +89,24 @@ def lib():
     L.bp_ctx_sync.restype = i32
     L.bp_verify_set_lanes.argtypes = [vp, i32]
     L.bp_verify_set_lanes.restype = None
+    L.bp_scalar_mul_batch.argtypes = [vp, cp, cp, sz, cp]
+    L.bp_scalar_mul_batch.restype = i32
+    L.bp_fold_bases.argtypes = [vp, cp, cp, sz, cp, cp, cp]
+    L.bp_fold_bases.restype = i32
+    L.bp_fixed_base_mul_batch.argtypes = [vp, cp, sz, cp]
+    L.bp_fixed_base_mul_batch.restype = i32
+    L.bp_generate_bases.argtypes = [i32, ctypes.c_uint64, sz, sz, cp, cp, cp, cp]
+    L.bp_generate_bases.restype = i32
+    prove_args = [vp, vp, i32, cp, cp, i32, cp, sz, cp, sz, ctypes.POINTER(sz)]
+    verify_args = [vp, vp, i32, i32, cp, sz, cp, i32, cp]
+    L.bp_rangeproof_prove.argtypes = prove_args
+    L.bp_rangeproof_prove.restype = i32
+    L.bp_wip_rangeproof_prove.argtypes = prove_args
+    L.bp_wip_rangeproof_prove.restype = i32
+    L.bp_rangeproof_verify.argtypes = verify_args
+    L.bp_rangeproof_verify.restype = i32
+    L.bp_wip_rangeproof_verify.argtypes = verify_args
+    L.bp_wip_rangeproof_verify.restype = i32
     L.bp_profile_enable.argtypes = [vp, i32]
     L.bp_profile_enable.restype = None
     L.bp_profile_reset.argtypes = [vp]
@@ -171,10 +197,70 @@ class Context:
         _check(lib().bp_rangeproof_verify_batch(self._h, gens._h, n_bits, m, proofs, proof_len, coms_xy, nproofs, out))
         return list(out.raw[:nproofs])
 
+    def scalar_mul_batch(self, points_xy, scalars_be):
+        n = len(scalars_be) // 32
+        out = ctypes.create_string_buffer(max(64 * n, 1))
+        _check(lib().bp_scalar_mul_batch(self._h, bytes(points_xy), bytes(scalars_be), n, out))
+        return out.raw[:64 * n]
+
+    def fold_bases(self, lo_xy, hi_xy, s_lo, s_hi):
+        n = len(lo_xy) // 64
+        out = ctypes.create_string_buffer(max(64 * n, 1))
+        _check(lib().bp_fold_bases(self._h, bytes(lo_xy), bytes(hi_xy), n, bytes(s_lo), bytes(s_hi), out))
+        return out.raw[:64 * n]
+
+    def fixed_base_mul_batch(self, scalars_be):
+        n = len(scalars_be) // 32
+        out = ctypes.create_string_buffer(max(64 * n, 1))
+        _check(lib().bp_fixed_base_mul_batch(self._h, bytes(scalars_be), n, out))
+        return out.raw[:64 * n]
+
+    def _prove(self, fn, gens, n_bits, secrets_be, blindings_be, tape):
+        m = len(secrets_be) // 32
+        out = ctypes.create_string_buffer(4096)
+        ln = ctypes.c_size_t(0)
+        _check(fn(self._h, gens._h, n_bits, bytes(secrets_be), bytes(blindings_be), m, bytes(tape), len(tape), out, 4096, ctypes.byref(ln)))
+        return out.raw[:ln.value]
+
+    def rangeproof_prove(self, gens, n_bits, secrets_be, blindings_be, tape):
+        """`RangeProof::prove`; tape = alpha, rho, SR[nm], SL[nm], tau1, tau2 (32-byte scalars)."""
+        return self._prove(lib().bp_rangeproof_prove, gens, n_bits, secrets_be, blindings_be, tape)
+
+    def wip_rangeproof_prove(self, gens, n_bits, secrets_be, blindings_be, tape):
+        """`RangeProofWIP::prove`; tape = alpha, (d_L, d_R) per round, r, s, delta, eta."""
+        return self._prove(lib().bp_wip_rangeproof_prove, gens, n_bits, secrets_be, blindings_be, tape)
+
+    def rangeproof_verify(self, gens, n_bits, m, proof, coms_xy, mode=2):
+        """mode 0 = verify, 1 = fast_verify, 2 = aggregated_verify -> verdict code."""
+        v = ctypes.create_string_buffer(1)
+        _check(lib().bp_rangeproof_verify(self._h, gens._h, n_bits, m, bytes(proof), len(proof), bytes(coms_xy), mode, v))
+        return v.raw[0]
+
+    def wip_rangeproof_verify(self, gens, n_bits, m, proof, coms_xy, mode=2):
+        """mode 0 = verify, 2 = aggregated_verify -> verdict code."""
+        v = ctypes.create_string_buffer(1)
+        _check(lib().bp_wip_rangeproof_verify(self._h, gens._h, n_bits, m, bytes(proof), len(proof), bytes(coms_xy), mode, v))
+        return v.raw[0]
+
     def rangeproof_verify_batch_device(self, gens, n_bits, m, d_proofs, proof_len, d_coms, nproofs, d_verdicts):
         """Asynchronous device-pointer variant (ints); call sync() before reading verdicts."""
         _check(lib().bp_rangeproof_verify_batch_device(self._h, gens._h, n_bits, m, ctypes.c_void_p(d_proofs), proof_len,
                                                        ctypes.c_void_p(d_coms), nproofs, ctypes.c_void_p(d_verdicts)))
+
+
+def generate_bases(kind, seed, n_bits, m):
+    """(g_xy, h_xy, G_xy, H_xy) bytes of the reference's generator recipe; kind 0 = Bulletproofs
+    tests/benches, 1 = StatementRP::generate_bases (Bulletproofs+).  Host-only, needs no GPU."""
+    nm = n_bits * m
+    g = ctypes.create_string_buffer(64 * nm)
+    h = ctypes.create_string_buffer(64 * nm)
+    G = ctypes.create_string_buffer(64)
+    H = ctypes.create_string_buffer(64)
+    _check(lib().bp_generate_bases(kind, seed, n_bits, m, g, h, G, H))
+    return g.raw, h.raw, G.raw, H.raw
+
+
+KZEN_SEED = int.from_bytes(bytes([75, 90, 101, 110]), "big")  # range_proof.rs:912-913
 
 
 class Gens:

@@ -136,7 +136,7 @@ static int upload_init(bp_ctx* ctx, const uint8_t* init_xy, const affine_mem** d
     return BP_OK;
 }
 
-static int fetch_result(bp_ctx* ctx, uint8_t out_xy[64]) {
+int msm_fetch_result(bp_ctx* ctx, uint8_t out_xy[64]) {
     int h_err = 0;
     uint8_t tmp[64];
     HIPCHK(hipMemcpyAsync(tmp, (uint8_t*)ctx->result.p + sizeof(affine_mem), 64, hipMemcpyDeviceToHost, ctx->stream), "memcpy out");
@@ -225,7 +225,7 @@ int bp_msm_device(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be
     const affine_mem* d_init;
     if ((rc = upload_init(ctx, init_xy, &d_init)) != BP_OK) return rc;
     if ((rc = msm_on_device(ctx, (const affine_mem*)ctx->points.p, (const uint8_t*)d_scalars_be, n, d_init)) != BP_OK) return rc;
-    return fetch_result(ctx, out_xy);
+    return msm_fetch_result(ctx, out_xy);
 }
 
 int bp_msm(bp_ctx* ctx, const uint8_t* points_xy, const uint8_t* scalars_be, size_t n, const uint8_t* init_xy, uint8_t out_xy[64]) {

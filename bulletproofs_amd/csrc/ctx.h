@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <mutex>
+#include <vector>
 
 #include "ec.h"
 
@@ -47,6 +48,7 @@ struct bp_ctx {
     bp::DevBuf in_points_be, in_scalars_be, points, digits, partial, wsum, result, initbuf;
     bp::DevBuf scratch[8];
     bp::DevBuf vartab, fixres;
+    bp::DevBuf proto[6];  // protocol layer (proto.cpp): folded bases, hi_tag, staging
     void release_all() {
         in_points_be.release();
         in_scalars_be.release();
@@ -59,9 +61,23 @@ struct bp_ctx {
         for (auto& s : scratch) s.release();
         vartab.release();
         fixres.release();
+        for (auto& s : proto) s.release();
     }
 };
 
+// Opaque `bp_gens` of include/bpmsm.h: generators in limb form + fixed-base window table in HBM.
+struct bp_gens {
+    int device = 0;
+    size_t nm = 0;
+    int np = 0;  // 2nm + 2
+    int c = 0, W = 0, NB = 0;
+    bp::affine_mem* d_pts = nullptr;    // g_vec, h_vec, G, H
+    bp::affine_mem* d_table = nullptr;  // [np][W][NB]
+    size_t table_bytes = 0;
+    std::vector<uint8_t> host_be;       // np * 64 bytes (x||y big-endian), for host-side transcript hashing
+};
+
 namespace bp {
+int msm_fetch_result(bp_ctx* ctx, uint8_t out_xy[64]);
 int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scalars_be, size_t n, const affine_mem* d_init);
 }

@@ -39,4 +39,11 @@ hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, cons
                           const int16_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st);
 size_t bpv_msm_vartab_bytes(int tp, size_t nproofs);
 
+
+// ecbatch_kernels.hip
+size_t ecbatch_vartab_bytes(size_t n);
+hipError_t launch_scalar_mul_batch(const affine_mem* pts, const uint8_t* scalars_be, size_t n, affine_mem* out, xyzz* vartab, hipStream_t st);
+hipError_t launch_fold_bases(const affine_mem* lo, const affine_mem* hi, size_t n_half, const uint8_t* s_lo_be, const uint8_t* s_hi_be,
+                             affine_mem* out, xyzz* vartab, hipStream_t st);
+
 }  // namespace bp

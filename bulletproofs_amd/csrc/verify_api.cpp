@@ -20,22 +20,12 @@ using namespace bp;
         }                          \
     } while (0)
 
-struct bp_gens {
-    int device = 0;
-    size_t nm = 0;
-    int np = 0;       // 2nm + 2
-    int c = 0, W = 0, NB = 0;
-    affine_mem* d_pts = nullptr;    // g_vec, h_vec, G, H (limb form)
-    affine_mem* d_table = nullptr;  // [np][W][NB]
-    size_t table_bytes = 0;
-};
-
 static int pick_table_window(int np) {
-    // largest c in [4, 12] whose table (np * W * 2^(c-1) * 64 B) stays <= 512 MiB
+    // largest c in [4, 14] whose table (np * W * 2^(c-1) * 64 B) stays <= 1.5 GiB of the 288 GB HBM
     int best = 4;
-    for (int c = 4; c <= 12; c++) {
+    for (int c = 4; c <= 14; c++) {
         size_t bytes = (size_t)np * (256 / c + 1) * ((size_t)1 << (c - 1)) * 64;
-        if (bytes <= ((size_t)512 << 20)) best = c;
+        if (bytes <= ((size_t)1536 << 20)) best = c;
     }
     return best;
 }
@@ -117,6 +107,7 @@ int bp_gens_create(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t
         bp_gens_destroy(g);
         return rc;
     }
+    g->host_be = host;
     *out = g;
     return BP_OK;
 }

@@ -71,7 +71,7 @@ void bp_msm_set_window(bp_ctx* ctx, int c);
 /* bp_gens — the shared generators g_vec[nm], h_vec[nm], G, H that the reference passes to every
  * prove/verify call as slices (range_proof.rs:46-49, 267-270, 539-542; StatementRP,
  * range_proof_wip.rs:39-45).  Uploaded once and expanded into a fixed-base window table in HBM
- * (window_bits = 0 picks a width whose table stays <= ~512 MiB); immutable afterwards.
+ * (window_bits = 0 picks the widest window whose table stays <= 1.5 GiB); immutable afterwards.
  * Infinity is not a valid generator (BP_EPOINT). */
 int bp_gens_create(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t nm, const uint8_t G_xy[64], const uint8_t H_xy[64],
                    int window_bits, bp_gens** out);
@@ -96,6 +96,55 @@ int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bi
 int bp_ctx_sync(bp_ctx* ctx);
 /* Tuning knob: lanes per proof in the verifier's MSM kernel (16, 32 or 64; 0 = default). */
 void bp_verify_set_lanes(bp_ctx* ctx, int lanes);
+
+/* bp_scalar_mul_batch — n independent out[i] = scalars[i] * points[i].
+ * Replaces `hi_tag[i] = &h_vec[i] * &yi_inv[i]` (range_proof.rs:231-233, 327-329, 462-464). */
+int bp_scalar_mul_batch(bp_ctx* ctx, const uint8_t* points_xy, const uint8_t* scalars_be, size_t n, uint8_t* out_xy);
+
+/* bp_fold_bases — out[i] = s_lo * lo[i] + s_hi * hi[i], i < n_half, shared scalars.
+ * Replaces G_new / H_new of the inner-product rounds (inner_product.rs:140-155, 203-218) and
+ * G_hat / H_hat of the weighted argument (weighted_inner_product.rs:189-204, 312-327). */
+int bp_fold_bases(bp_ctx* ctx, const uint8_t* lo_xy, const uint8_t* hi_xy, size_t n_half, const uint8_t s_lo[32], const uint8_t s_hi[32],
+                  uint8_t* out_xy);
+
+/* bp_fixed_base_mul_batch — out[i] = scalars[i] * G (secp256k1 generator).
+ * Replaces `base_point * &y`, `G * &challenge_x`, `G * &x_u_fe` (range_proof.rs:126, 219, 588). */
+int bp_fixed_base_mul_batch(bp_ctx* ctx, const uint8_t* scalars_be, size_t n, uint8_t* out_xy);
+
+/* bp_generate_bases — the synthetic generator recipe (host-side, no GPU):
+ *   kind 0: the Bulletproofs tests/benches (range_proof.rs:821-843, benches/range_proof.rs:43-67):
+ *           G = generator, H = grp(SHA512(1)), g_i = grp(SHA512(seed+i)), h_i = grp(SHA512(seed+n+i));
+ *   kind 1: StatementRP::generate_bases (range_proof_wip.rs:48-91): as above with H = grp(SHA512(seed-1)).
+ * grp = generate_random_point (range_proof.rs:785-808).  g_xy / h_xy receive n_bits*m points. */
+int bp_generate_bases(int kind, uint64_t seed, size_t n_bits, size_t m, uint8_t* g_xy, uint8_t* h_xy, uint8_t G_xy[64], uint8_t H_xy[64]);
+
+/* bp_rangeproof_prove — `RangeProof::prove` (range_proof.rs:45-263) + `InnerProductArg::prove`
+ * (inner_product.rs:36-169).  secrets_be / blindings_be: m scalars of 32 bytes.  The reference draws
+ * its randomness from the OS (`Scalar::random()`), so the caller supplies it: `tape` holds 2nm+4
+ * scalars in [1, q) in the reference's draw order alpha, rho, SR[0..nm), SL[0..nm), tau1, tau2.
+ * Output: canonical proof encoding (292 + 66 log2(nm) bytes), bit-identical to the oracle's. */
+int bp_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint8_t* secrets_be, const uint8_t* blindings_be, int m,
+                        const uint8_t* tape, size_t tape_len, uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
+
+/* bp_rangeproof_verify — one proof through `RangeProof::verify` (mode 0, range_proof.rs:265-398, with
+ * the recursive `InnerProductArg::verify`), `fast_verify` (mode 1, :400-535 + inner_product.rs:253-345)
+ * or `aggregated_verify` (mode 2, :537-782).  *verdict receives a BP_VERDICT_* code. */
+#define BP_MODE_VERIFY 0
+#define BP_MODE_FAST_VERIFY 1
+#define BP_MODE_AGGREGATED_VERIFY 2
+int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proof, size_t proof_len, const uint8_t* coms_xy,
+                         int mode, uint8_t* verdict);
+
+/* Bulletproofs+ : `RangeProofWIP::prove` (range_proof_wip.rs:101-274) with
+ * `WeightedInnerProdArg::prove` (weighted_inner_product.rs:47-268); tape = alpha, then (d_L, d_R) per
+ * round, then r, s, delta, eta (1 + 2 log2(nm) + 4 scalars).  Proof = 195 + 66 log2(nm) bytes.
+ * gens must come from the StatementRP recipe (bp_generate_bases kind 1) for reference-shaped inputs. */
+int bp_wip_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint8_t* secrets_be, const uint8_t* blindings_be, int m,
+                            const uint8_t* tape, size_t tape_len, uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
+/* `RangeProofWIP::verify` (mode 0, :276-382, through `WeightedInnerProdArg::fast_verify`) or
+ * `aggregated_verify` (mode 2, :388-609). */
+int bp_wip_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proof, size_t proof_len,
+                             const uint8_t* coms_xy, int mode, uint8_t* verdict);
 
 /* Per-kernel device timing with HIP events on the context's own stream (what bench.py's roofline
  * block reads; no reference counterpart).  Kernel ids: 0 = bpv_decompress, 1 = bpv_scalars,

@@ -1,0 +1,120 @@
+"""GPU parity of the protocol layer (C ABI: bp_rangeproof_prove / _verify, bp_wip_*, bp_fold_bases,
+bp_scalar_mul_batch, bp_fixed_base_mul_batch): proof BYTES identical to the golden fixtures for the
+same randomness tape, and verdicts identical to the oracle's on valid and tampered proofs."""
+import random
+
+import pytest
+
+import bulletproofs_amd as bpa
+from oracle import ec
+
+from _golden import VERDICT_CODE, bp_cases, bpplus_cases, load
+
+pytestmark = pytest.mark.gpu
+
+
+def _gens(ctx, kind, n, m, wb=6):
+    g, h, G, H = bpa.generate_bases(kind, bpa.KZEN_SEED, n, m)
+    return bpa.Gens(ctx, g, h, G, H, wb)
+
+
+def _be(xs):
+    return b"".join(int(x, 16).to_bytes(32, "big") for x in xs)
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_bp_prove_bytes_match_golden(ctx, idx):
+    case = bp_cases()[idx]
+    n, m = case["n"], case["m"]
+    gens = _gens(ctx, 0, n, m)
+    try:
+        proof = ctx.rangeproof_prove(gens, n, _be(case["secrets"]), _be(case["blindings"]), bytes.fromhex(case["tape"]))
+        assert proof.hex() == case["proof"]
+    finally:
+        gens.close()
+
+
+def test_bp_prove_c2_n64_m16(ctx):
+    case = load("bp_c2_n64_m16.json")
+    gens = _gens(ctx, 0, 64, 16)
+    try:
+        proof = ctx.rangeproof_prove(gens, 64, _be(case["secrets"]), _be(case["blindings"]), bytes.fromhex(case["tape"]))
+        assert proof.hex() == case["proof"]
+        coms = b"".join(bytes.fromhex(c) for c in case["commitments"])
+        assert ctx.rangeproof_verify(gens, 64, 16, proof, coms, 2) == 0
+        assert ctx.rangeproof_verify(gens, 64, 16, proof, coms, 1) == 0
+    finally:
+        gens.close()
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_bp_verify_modes_agree_with_oracle(ctx, idx):
+    """verify == fast_verify == aggregated_verify (the reference's three verifiers) on honest and tampered proofs."""
+    case = bp_cases()[idx]
+    n, m = case["n"], case["m"]
+    gens = _gens(ctx, 0, n, m)
+    try:
+        items = [(case["proof"], case["commitments"], case["verdict"])] + [(t["proof"], t["commitments"], t["verdict"]) for t in case["tampered"]]
+        for pf, cm, want in items:
+            coms = b"".join(bytes.fromhex(c) for c in cm)
+            for mode in (0, 1, 2):
+                assert ctx.rangeproof_verify(gens, n, m, bytes.fromhex(pf), coms, mode) == VERDICT_CODE[want], (mode, want)
+    finally:
+        gens.close()
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_bpplus_prove_and_verify(ctx, idx):
+    case = bpplus_cases()[idx]
+    n, m = case["n"], case["m"]
+    gens = _gens(ctx, 1, n, m)
+    try:
+        proof = ctx.wip_rangeproof_prove(gens, n, _be(case["secrets"]), _be(case["blindings"]), bytes.fromhex(case["tape"]))
+        assert proof.hex() == case["proof"]
+        items = [(case["proof"], case["commitments"], case["verdict"])] + [(t["proof"], t["commitments"], t["verdict"]) for t in case["tampered"]]
+        for pf, cm, want in items:
+            coms = b"".join(bytes.fromhex(c) for c in cm)
+            for mode in (0, 2):
+                assert ctx.wip_rangeproof_verify(gens, n, m, bytes.fromhex(pf), coms, mode) == VERDICT_CODE[want], (mode, want)
+    finally:
+        gens.close()
+
+
+def test_out_of_range_secret_is_rejected(ctx, oracle_c):
+    """range_proof.rs:955-1006 / range_proof_wip.rs:703-736 (#[should_panic]): v >= 2^n does not verify."""
+    from oracle import tape
+    n, m = 8, 2
+    for kind, prove, verify in ((0, ctx.rangeproof_prove, ctx.rangeproof_verify), (1, ctx.wip_rangeproof_prove, ctx.wip_rangeproof_verify)):
+        g, h, G, H = bpa.generate_bases(kind, bpa.KZEN_SEED, n, m)
+        gens = bpa.Gens(ctx, g, h, G, H, 6)
+        try:
+            tb = tape.make_tape_bytes("oor%d" % kind, m + 2 * n * m + 4)
+            v = [3, 1 << (n + 1)]
+            r = [int.from_bytes(tb[32 * j:32 * j + 32], "big") for j in range(m)]
+            Gp, Hp = ec.dec64(G), ec.dec64(H)
+            coms = b"".join(ec.enc64(oracle_c.add(oracle_c.mul(Gp, v[j]), oracle_c.mul(Hp, r[j]))) for j in range(m))
+            proof = prove(gens, n, b"".join(x.to_bytes(32, "big") for x in v), tb[:32 * m], tb[32 * m:])
+            assert verify(gens, n, m, proof, coms, 2) == 3
+            assert verify(gens, n, m, proof, coms, 0) == 3
+        finally:
+            gens.close()
+
+
+def test_group_primitives(ctx, oracle_c):
+    rng = random.Random(77)
+    n = 37
+    pts = oracle_c.mul_batch([ec.G] * (2 * n), [rng.randrange(1, ec.Q) for _ in range(2 * n)])
+    ks = [rng.randrange(ec.Q) for _ in range(n)]
+    ks[0], ks[1], ks[2] = 0, 1, ec.Q - 1
+    pb = b"".join(ec.enc64(p) for p in pts)
+    got = ctx.scalar_mul_batch(pb[:64 * n], b"".join(k.to_bytes(32, "big") for k in ks))
+    assert got == b"".join(ec.enc64(p) for p in oracle_c.mul_batch(pts[:n], ks))
+    s_lo, s_hi = rng.randrange(1, ec.Q), rng.randrange(1, ec.Q)
+    got = ctx.fold_bases(pb[:64 * n], pb[64 * n:], s_lo.to_bytes(32, "big"), s_hi.to_bytes(32, "big"))
+    want = [oracle_c.add(oracle_c.mul(pts[i], s_lo), oracle_c.mul(pts[n + i], s_hi)) for i in range(n)]
+    assert got == b"".join(ec.enc64(p) for p in want)
+    # duplicates / opposite points fold to 2P-ish and infinity correctly
+    got = ctx.fold_bases(pb[:64], ec.enc64(ec.neg(pts[0])), (5).to_bytes(32, "big"), (5).to_bytes(32, "big"))
+    assert got == b"\0" * 64
+    got = ctx.fixed_base_mul_batch(b"".join(k.to_bytes(32, "big") for k in ks))
+    assert got == b"".join(ec.enc64(p) for p in oracle_c.mul_batch([ec.G] * n, ks))
