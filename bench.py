@@ -39,9 +39,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--proofs-per-gpu", type=int, default=4096)
+    ap.add_argument("--proofs-per-gpu", type=int, default=16384)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per proof in k_bpv_msm (16/32/64)")
     ap.add_argument("--window-bits", type=int, default=0, help="fixed-base table window (0 = auto)")
+    ap.add_argument("--workload", default="verify", choices=["verify", "msm"],
+                    help="verify = headline metric (default); msm = raw 2^20-point Pippenger MSM, points sharded over the ranks")
+    ap.add_argument("--msm-log2", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-check", action="store_true", help="timing experiments only: do not compare verdicts")
     ap.add_argument("--cpu-sample", type=int, default=96, help="proofs verified by the CPU baseline")
@@ -86,8 +89,91 @@ def cpu_baseline(batch, sample):
             "sample": "%d n=64 m=1 proofs, oracle aggregated_verify (term-by-term MSM in C, as range_proof.rs:772-774)" % done}
 
 
+def bench_msm(args):
+    """BASELINE.json configs[4]: raw Pippenger MSM of 2^k secp256k1 points; points sharded N/G per rank,
+    per-rank partial sums all-gathered over RCCL and added (bulletproofs_amd/batch.py: msm_sharded).
+    Strong scaling (total work fixed).  Inputs resident in HBM; the 64-byte result returns to the host."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    import bulletproofs_amd as bpa
+    from bulletproofs_amd import batch as bt
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    N = 1 << args.msm_log2
+    lo, hi = bt.shard_range(N, rank, world)
+    n = hi - lo
+    ctx = bpa.Context(local_rank)
+    # synthetic points P_i = r_i * G (tape scalars) made on the GPU; scalars from a SHA-256 counter stream
+    def stream(tag, count, start):
+        out = bytearray()
+        for i in range(start, start + count):
+            out += hashlib.sha256(b"bpmsm-c5-%s-%d" % (tag, i)).digest()
+        return bytes(out)
+    pts = bytearray()
+    CH = 1 << 16
+    for s0 in range(lo, hi, CH):
+        c = min(CH, hi - s0)
+        pts += ctx.fixed_base_mul_batch(stream(b"r", c, s0))
+    scal = stream(b"k", n, lo)
+    d_pts = torch.frombuffer(pts, dtype=torch.uint8).to(dev)
+    d_sc = torch.frombuffer(bytearray(scal), dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()
+
+    def step():
+        part = ctx.msm_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
+        if world == 1:
+            return part
+        buf = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev)
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+        allp = b"".join(bytes(p.cpu().numpy().tobytes()) for p in parts)
+        return ctx.msm(allp, (1).to_bytes(32, "big") * world)
+
+    for _ in range(args.warmup):
+        res = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        mpts = N * args.steps / dt / 1e6
+        mad_per_point = 11833.0  # SURVEY.md §8(d), C5 model (c = 16)
+        print(json.dumps({
+            "metric": "MSM Mpts/s (raw Pippenger MSM, secp256k1)", "value": mpts, "unit": "Mpts/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32 (256-bit modular integer arithmetic)",
+            "data": "synthetic (P_i = r_i*G, SHA-256 counter-stream scalars)",
+            "config": {"workload": "raw MSM of 2^%d points, points sharded over %d GPU(s), partial sums all-gathered" % (args.msm_log2, world),
+                       "result": res.hex()},
+            "roofline": {"bound": "valu_int32_mad", "kernel": "k_msm_slice", "achieved": mpts * 1e6 * mad_per_point / world / 1e12,
+                         "peak": PEAK_MAD32_PER_S / 1e12, "unit": "TMAD32/s", "frac": mpts * 1e6 * mad_per_point / world / PEAK_MAD32_PER_S,
+                         "traffic": None}}), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.workload == "msm":
+        return bench_msm(args)
     import torch
     import torch.distributed as dist
     import bulletproofs_amd as bpa

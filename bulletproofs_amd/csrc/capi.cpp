@@ -48,6 +48,7 @@ void DevBuf::release() {
 MsmPlan plan_msm(size_t n, int forced_c) {
     MsmPlan pl;
     int c;
+    if (const char* e = getenv("BP_MSM_C")) forced_c = atoi(e);  // tuning experiments
     if (forced_c >= 2 && forced_c <= 12)
         c = forced_c;
     else if (n <= 32)
@@ -64,10 +65,8 @@ MsmPlan plan_msm(size_t n, int forced_c) {
         c = 8;
     else if (n <= 65536)
         c = 9;
-    else if (n <= 262144)
-        c = 10;
     else
-        c = 11;
+        c = 10;  // measured at 2^20 points: c = 10 / 8192-point slices beats c = 11 / 16384 by 8x
     pl.c = c;
     pl.W = 256 / c + 1;
     int NB = 1 << (c - 1);
@@ -75,8 +74,9 @@ MsmPlan plan_msm(size_t n, int forced_c) {
     // slice length: enough points per bucket to amortise the in-LDS reduction, enough slices to fill 256 CUs
     size_t M = (size_t)NB * 16;
     if (M < 256) M = 256;
-    if (M > 16384) M = 16384;
+    if (M > 8192) M = 8192;
     while (M > (size_t)NB * 4 && M > 256 && ((n + M - 1) / M) * pl.W < 512) M /= 2;
+    if (const char* e = getenv("BP_MSM_M")) M = (size_t)atol(e);
     if (M > n && n > 0) M = n;
     if (M == 0) M = 1;
     pl.M = (int)M;

@@ -188,6 +188,10 @@ def main():
     with open(os.path.join(HERE, "bpplus_cases.json"), "w") as f:
         json.dump(plus, f)
 
+    print("bp+ 64x64 (config C4)", flush=True)
+    with open(os.path.join(HERE, "bpplus_c4_n64_m64.json"), "w") as f:
+        json.dump(make_bpplus(64, 64, "c4"), f)
+
     # C3 batch: 256 distinct n=64 m=1 proofs with the shared generators (bench.py tiles them)
     print("c3 batch", flush=True)
     with mp.Pool(8) as pool:

@@ -48,7 +48,20 @@ def _worker(rank, world, port, q):
 
     got = batch.verify_batch_sharded(verify_fn, proofs, plen, coms, 64, len(items))
     lo, hi = batch.shard_range(len(items), rank, world)
-    q.put((rank, got == want, hi - lo))
+    # point-sharded MSM with an all-gather of the per-rank partial sums
+    import random
+    rng = random.Random(5)
+    pts = [ec.mul(ec.G, rng.randrange(1, ec.Q)) for _ in range(11)]
+    ks = [rng.randrange(ec.Q) for _ in range(11)]
+
+    def msm_fn(pb, sb):
+        pp = [ec.dec64(pb[i:i + 64]) for i in range(0, len(pb), 64)]
+        kk = [int.from_bytes(sb[i:i + 32], "big") for i in range(0, len(sb), 32)]
+        return ec.enc64(ec.msm_naive(pp, kk, None))
+
+    msm_got = batch.msm_sharded(msm_fn, b"".join(ec.enc64(p) for p in pts), b"".join(k.to_bytes(32, "big") for k in ks))
+    msm_ok = msm_got == ec.enc64(ec.msm_naive(pts, ks, None))
+    q.put((rank, got == want and msm_ok, hi - lo))
     dist.destroy_process_group()
 
 

@@ -118,3 +118,20 @@ def test_group_primitives(ctx, oracle_c):
     assert got == b"\0" * 64
     got = ctx.fixed_base_mul_batch(b"".join(k.to_bytes(32, "big") for k in ks))
     assert got == b"".join(ec.enc64(p) for p in oracle_c.mul_batch([ec.G] * n, ks))
+
+
+def test_bpplus_c4_n64_m64(ctx):
+    """BASELINE.json configs[3]: Bulletproofs+ aggregated n=64 m=64 prove + verify (MSM of 8284 terms)."""
+    case = load("bpplus_c4_n64_m64.json")
+    gens = _gens(ctx, 1, 64, 64, 4)
+    try:
+        proof = ctx.wip_rangeproof_prove(gens, 64, _be(case["secrets"]), _be(case["blindings"]), bytes.fromhex(case["tape"]))
+        assert len(proof) == 987 and proof.hex() == case["proof"]
+        items = [(case["proof"], case["commitments"], case["verdict"])] + [(t["proof"], t["commitments"], t["verdict"]) for t in case["tampered"]]
+        for pf, cm, want in items:
+            coms = b"".join(bytes.fromhex(c) for c in cm)
+            assert ctx.wip_rangeproof_verify(gens, 64, 64, bytes.fromhex(pf), coms, 2) == VERDICT_CODE[want]
+        coms = b"".join(bytes.fromhex(c) for c in case["commitments"])
+        assert ctx.wip_rangeproof_verify(gens, 64, 64, proof, coms, 0) == 0
+    finally:
+        gens.close()
