@@ -17,6 +17,7 @@ EXPORTED_SYMBOLS = [
     "bp_msm",
     "bp_msm_device",
     "bp_msm_set_window",
+    "bp_msm_set_path",
     "bp_gens_create",
     "bp_gens_destroy",
     "bp_gens_table_bytes",
@@ -75,6 +76,8 @@ def lib():
     L.bp_msm_device.restype = i32
     L.bp_msm_set_window.argtypes = [vp, i32]
     L.bp_msm_set_window.restype = None
+    L.bp_msm_set_path.argtypes = [vp, i32]
+    L.bp_msm_set_path.restype = None
     L.bp_gens_create.argtypes = [vp, cp, cp, sz, cp, cp, i32, ctypes.POINTER(vp)]
     L.bp_gens_create.restype = i32
     L.bp_gens_destroy.argtypes = [vp]
@@ -149,6 +152,10 @@ class Context:
 
     def set_window(self, c):
         lib().bp_msm_set_window(self._h, c)
+
+    def set_path(self, path):
+        """0 = automatic, 1 = LDS slice path, 2 = global sorted path (testing / tuning)."""
+        lib().bp_msm_set_path(self._h, path)
 
     def msm(self, points_xy, scalars_be, init_xy=None):
         """out = init + sum scalars[i]*points[i]; bytes in, 64 bytes out (see include/bpmsm.h)."""

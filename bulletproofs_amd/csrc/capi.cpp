@@ -44,44 +44,84 @@ void DevBuf::release() {
     cap = 0;
 }
 
-// Window width / slicing plan for an n-point MSM (see msm_kernels.hip).
-MsmPlan plan_msm(size_t n, int forced_c) {
+// Number of signed c-bit windows covering a GLV half-scalar (|k| < 2^129) and its recoding carry.
+static int glv_windows(int c) { return (129 + c) / c; }
+
+// Window width / slicing plan for the LDS path over n2 = 2n virtual (GLV) points (see msm_kernels.hip).
+MsmPlan plan_msm(size_t n2, int forced_c) {
     MsmPlan pl;
     int c;
     if (const char* e = getenv("BP_MSM_C")) forced_c = atoi(e);  // tuning experiments
     if (forced_c >= 2 && forced_c <= 12)
         c = forced_c;
-    else if (n <= 32)
+    else if (n2 <= 32)
         c = 3;
-    else if (n <= 96)
+    else if (n2 <= 96)
         c = 4;
-    else if (n <= 384)
+    else if (n2 <= 384)
         c = 5;
-    else if (n <= 1024)
+    else if (n2 <= 1024)
         c = 6;
-    else if (n <= 3072)
+    else if (n2 <= 3072)
         c = 7;
-    else if (n <= 12288)
+    else if (n2 <= 12288)
         c = 8;
-    else if (n <= 65536)
+    else if (n2 <= 65536)
         c = 9;
     else
-        c = 10;  // measured at 2^20 points: c = 10 / 8192-point slices beats c = 11 / 16384 by 8x
+        c = 10;
     pl.c = c;
-    pl.W = 256 / c + 1;
+    pl.W = glv_windows(c);
     int NB = 1 << (c - 1);
     pl.T = NB >= 256 ? 256 : (NB >= 128 ? 128 : 64);
     // slice length: enough points per bucket to amortise the in-LDS reduction, enough slices to fill 256 CUs
     size_t M = (size_t)NB * 16;
     if (M < 256) M = 256;
     if (M > 8192) M = 8192;
-    while (M > (size_t)NB * 4 && M > 256 && ((n + M - 1) / M) * pl.W < 512) M /= 2;
+    while (M > (size_t)NB * 4 && M > 256 && ((n2 + M - 1) / M) * pl.W < 512) M /= 2;
     if (const char* e = getenv("BP_MSM_M")) M = (size_t)atol(e);
-    if (M > n && n > 0) M = n;
+    if (M > n2 && n2 > 0) M = n2;
     if (M == 0) M = 1;
     pl.M = (int)M;
-    pl.S = n ? (int)((n + M - 1) / M) : 1;
+    pl.S = n2 ? (int)((n2 + M - 1) / M) : 1;
     pl.npad = (size_t)pl.S * M;
+    return pl;
+}
+
+// Plan of the sorted (large-N) path (msm_sorted.hip).  Cost model: W * (n2 + 3 NB) mixed-add
+// equivalents (bucket accumulation + finalize/row/column additions); c <= 15 (int16 digits, 64 KB
+// LDS histograms).
+SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
+    SortedPlan pl;
+    if (const char* e = getenv("BP_MSM_C")) forced_c = atoi(e);
+    int c = 0;
+    if (forced_c >= 2 && forced_c <= 15) {
+        c = forced_c;
+    } else {
+        double best = 0;
+        for (int cc = 6; cc <= 15; cc++) {
+            double cost = (double)glv_windows(cc) * ((double)n2 + 3.0 * (double)(1 << (cc - 1)));
+            if (c == 0 || cost < best) {
+                best = cost;
+                c = cc;
+            }
+        }
+    }
+    pl.c = c;
+    pl.W = glv_windows(c);
+    pl.NB = 1 << (c - 1);
+    // chunk of points per histogram workgroup: ~512 workgroups in flight, 4096..65536 points each
+    size_t ch = 4096;
+    while (ch < 65536 && ((n2 + ch - 1) / ch) * (size_t)pl.W > 512) ch *= 2;
+    pl.CH = (int)ch;
+    pl.nchunks = (int)((n2 + ch - 1) / ch);
+    if (pl.nchunks < 1) pl.nchunks = 1;
+    pl.npad = (size_t)pl.nchunks * ch;
+    pl.L = 32;
+    if (const char* e = getenv("BP_MSM_L")) pl.L = atoi(e) > 0 ? atoi(e) : 32;
+    pl.nseg = (int)((pl.npad + pl.L - 1) / pl.L);
+    pl.lo_bits = c / 2;  // LO = 2^lo_bits, HI = NB / LO; LO + HI <= 256 for c <= 15
+    if (pl.lo_bits > c - 1) pl.lo_bits = c - 1;
     return pl;
 }
 
@@ -96,13 +136,12 @@ MsmPlan plan_msm(size_t n, int forced_c) {
 
 // out = init + sum scalars[i] * points[i]; d_points (limb form) and d_scalars_be on device.
 // Leaves the result in ctx->d_result (limb form) and ctx->d_result_be; does not synchronise.
+// Path: GLV split (2n virtual points, 129-bit scalars) -> LDS slice path (small / medium n) or
+// global sorted path (large n) -> Horner over the windows.
 int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scalars_be, size_t n, const affine_mem* d_init) {
     hipStream_t st = ctx->stream;
-    MsmPlan pl = plan_msm(n, ctx->forced_c);
     int rc;
-    if ((rc = ctx->digits.reserve((size_t)pl.W * pl.npad * sizeof(int16_t))) != BP_OK) return rc;
-    if ((rc = ctx->partial.reserve((size_t)pl.W * pl.S * sizeof(xyzz))) != BP_OK) return rc;
-    if ((rc = ctx->wsum.reserve((size_t)pl.W * sizeof(xyzz))) != BP_OK) return rc;
+    if ((rc = ctx->wsum.reserve(64 * sizeof(xyzz))) != BP_OK) return rc;
     if ((rc = ctx->result.reserve(sizeof(affine_mem) + 64)) != BP_OK) return rc;
     affine_mem* d_res = (affine_mem*)ctx->result.p;
     uint8_t* d_res_be = (uint8_t*)ctx->result.p + sizeof(affine_mem);
@@ -112,14 +151,59 @@ int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scal
         HIPCHK(launch_msm_horner((const xyzz*)ctx->wsum.p, 1, 1, d_init, d_res, d_res_be, st), "horner");
         return BP_OK;
     }
-    if (msm_slice_lds_bytes(pl.c, pl.M, pl.T) > 160 * 1024) {
-        set_error_msg("msm plan exceeds LDS");
+    if (n >= ((size_t)1 << 30)) {
+        set_error_msg("msm: more than 2^30 terms");
         return BP_EINVAL;
     }
-    HIPCHK(launch_scalars_to_digits(d_scalars_be, n, pl.npad, pl.c, pl.W, (int16_t*)ctx->digits.p, st), "digits");
-    HIPCHK(launch_msm_slice(d_points, (const int16_t*)ctx->digits.p, n, pl.npad, pl.M, pl.c, pl.W, pl.S, pl.T, (xyzz*)ctx->partial.p, st), "slice");
-    HIPCHK(launch_msm_reduce_slices((const xyzz*)ctx->partial.p, pl.S, pl.W, (xyzz*)ctx->wsum.p, st), "reduce");
-    HIPCHK(launch_msm_horner((const xyzz*)ctx->wsum.p, pl.W, pl.c, d_init, d_res, d_res_be, st), "horner");
+    const size_t n2 = 2 * n;
+    int path = ctx->msm_path;  // 0 auto, 1 LDS slices, 2 sorted
+    if (const char* e = getenv("BP_MSM_PATH")) path = atoi(e);
+    if (path == 0) path = n2 >= ((size_t)1 << 15) ? 2 : 1;
+    if ((rc = ctx->lam.reserve(n * sizeof(affine_mem))) != BP_OK) return rc;
+    HIPCHK(launch_glv_expand(d_points, (affine_mem*)ctx->lam.p, n, st), "glv expand");
+    const affine_mem* lam = (const affine_mem*)ctx->lam.p;
+    int c, W;
+    if (path == 1) {
+        MsmPlan pl = plan_msm(n2, ctx->forced_c);
+        c = pl.c;
+        W = pl.W;
+        if (msm_slice_lds_bytes(pl.c, pl.M, pl.T) > 64 * 1024) {
+            set_error_msg("msm plan exceeds LDS");
+            return BP_EINVAL;
+        }
+        if ((rc = ctx->digits.reserve((size_t)pl.W * pl.npad * sizeof(int16_t))) != BP_OK) return rc;
+        if ((rc = ctx->partial.reserve((size_t)pl.W * pl.S * sizeof(xyzz))) != BP_OK) return rc;
+        HIPCHK(launch_glv_digits(d_scalars_be, n, pl.npad, pl.c, pl.W, (int16_t*)ctx->digits.p, st), "digits");
+        HIPCHK(launch_msm_slice(d_points, lam, n, (const int16_t*)ctx->digits.p, n2, pl.npad, pl.M, pl.c, pl.W, pl.S, pl.T, (xyzz*)ctx->partial.p, st),
+               "slice");
+        HIPCHK(launch_msm_reduce_slices((const xyzz*)ctx->partial.p, pl.S, pl.W, (xyzz*)ctx->wsum.p, st), "reduce");
+    } else {
+        SortedPlan pl = plan_msm_sorted(n2, ctx->forced_c);
+        c = pl.c;
+        W = pl.W;
+        const size_t NB = pl.NB;
+        const size_t nout = ((size_t)1 << pl.lo_bits) + (NB >> pl.lo_bits);
+        if ((rc = ctx->digits.reserve((size_t)W * pl.npad * sizeof(int16_t))) != BP_OK) return rc;
+        if ((rc = ctx->srt[0].reserve((size_t)W * pl.nchunks * NB * 4)) != BP_OK) return rc;
+        if ((rc = ctx->srt[1].reserve((size_t)W * (NB + 1) * 4 + ((size_t)W * NB + 1) * 4)) != BP_OK) return rc;
+        if ((rc = ctx->srt[2].reserve((size_t)W * pl.npad * 4)) != BP_OK) return rc;
+        if ((rc = ctx->srt[3].reserve((size_t)W * pl.npad * 2)) != BP_OK) return rc;
+        if ((rc = ctx->srt[4].reserve((size_t)W * NB * sizeof(xyzz))) != BP_OK) return rc;
+        if ((rc = ctx->srt[5].reserve((size_t)W * pl.nseg * sizeof(xyzz))) != BP_OK) return rc;
+        if ((rc = ctx->srt[6].reserve((size_t)W * nout * sizeof(xyzz))) != BP_OK) return rc;
+        SortedBufs b;
+        b.cnt = (uint32_t*)ctx->srt[0].p;
+        b.bstart = (uint32_t*)ctx->srt[1].p;
+        b.queue = b.bstart + (size_t)W * (NB + 1);
+        b.ent = (uint32_t*)ctx->srt[2].p;
+        b.bkt = (uint16_t*)ctx->srt[3].p;
+        b.Bk = (xyzz*)ctx->srt[4].p;
+        b.Pseg = (xyzz*)ctx->srt[5].p;
+        b.RC = (xyzz*)ctx->srt[6].p;
+        HIPCHK(launch_glv_digits(d_scalars_be, n, pl.npad, pl.c, pl.W, (int16_t*)ctx->digits.p, st), "digits");
+        HIPCHK(launch_msm_sorted(d_points, lam, n, (const int16_t*)ctx->digits.p, n2, pl, b, (xyzz*)ctx->wsum.p, st), "sorted msm");
+    }
+    HIPCHK(launch_msm_horner((const xyzz*)ctx->wsum.p, W, c, d_init, d_res, d_res_be, st), "horner");
     return BP_OK;
 }
 
@@ -212,6 +296,9 @@ void bp_ctx_destroy(bp_ctx* ctx) {
 
 void bp_msm_set_window(bp_ctx* ctx, int c) {
     if (ctx) ctx->forced_c = c;
+}
+void bp_msm_set_path(bp_ctx* ctx, int path) {
+    if (ctx) ctx->msm_path = (path == 1 || path == 2) ? path : 0;
 }
 
 int bp_msm_device(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be, size_t n, const uint8_t* init_xy, uint8_t out_xy[64]) {

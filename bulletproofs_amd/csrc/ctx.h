@@ -23,7 +23,7 @@ struct MsmPlan {
     int c, W, T, M, S;
     size_t npad;
 };
-MsmPlan plan_msm(size_t n, int forced_c);
+MsmPlan plan_msm(size_t n2, int forced_c);
 
 void set_error(const char* where, hipError_t e);
 void set_error_msg(const char* msg);
@@ -35,6 +35,7 @@ struct bp_ctx {
     hipStream_t stream = nullptr;
     int* d_err = nullptr;
     int forced_c = 0;
+    int msm_path = 0;  // 0 auto, 1 LDS slice path, 2 sorted path (bp_msm_set_path)
     int verify_lanes = 0;
     // optional per-kernel timing (bp_profile_*): HIP events on this context's stream
     bool profiling = false;
@@ -46,6 +47,8 @@ struct bp_ctx {
     long prof_calls[kMaxProf] = {};
     std::mutex mu;
     bp::DevBuf in_points_be, in_scalars_be, points, digits, partial, wsum, result, initbuf;
+    bp::DevBuf lam;     // lambda(P_i) = (beta x_i, y_i), the GLV images of the current MSM's points
+    bp::DevBuf srt[7];  // sorted-path workspaces (msm_sorted.hip)
     bp::DevBuf scratch[8];
     bp::DevBuf vartab, fixres;
     bp::DevBuf proto[6];  // protocol layer (proto.cpp): folded bases, hi_tag, staging
@@ -58,6 +61,8 @@ struct bp_ctx {
         wsum.release();
         result.release();
         initbuf.release();
+        lam.release();
+        for (auto& s : srt) s.release();
         for (auto& s : scratch) s.release();
         vartab.release();
         fixres.release();

@@ -144,23 +144,30 @@ BP_HD fp fp_neg(const fp& a) { return fp_sub(fp_zero(), a); }
 BP_HD fp fp_dbl(const fp& a) { return fp_add(a, a); }
 BP_HD bool fp_eq(const fp& a, const fp& b) { return fp_is_zero(fp_sub(a, b)); }
 
-// Reduce 18 product limbs r[0..17] (29 bits each, r[17] small) modulo p.
-// 2^261 = 2^5 (2^32 + 977) = 256 * 2^29 + 31264  (mod p).
-BP_HD fp fp_fold18(const uint32_t r[18]) {
+// Reduce a 9x9 product given as
+//   L[0..8]  the low columns, each a raw 64-bit sum of <= 9 products (< 2^61.2, NOT carry-propagated),
+//   H[0..8]  the high columns 9..17 carry-propagated to 29-bit limbs (H[8], the final carry, < 2^21),
+// modulo p.  2^261 = 2^5 (2^32 + 977) = 256 * 2^29 + 31264 (mod p), so high limb H[k] (weight
+// 2^261 * 2^(29k)) adds 31264*H[k] to column k and 256*H[k] to column k+1: two more MADs per column
+// with the low column as the addend, then ONE carry pass over the nine sums.  (Carry-propagating
+// the low columns first, as a textbook product scan does, costs an and + 64-bit shift + 64-bit add
+// per column for nothing: only the high half has to be split into 29-bit multiplier operands.)
+BP_HD fp fp_fold_cols(const uint64_t L[9], const uint32_t H[9]) {
     fp o;
-    uint64_t c = (uint64_t)r[9] * 31264u + r[0];
+    uint64_t c = L[0] + (uint64_t)H[0] * 31264u;
     o.v[0] = (uint32_t)c & BP_M29;
     c >>= 29;
 #pragma unroll
     for (int k = 1; k < 9; k++) {
-        c += (uint64_t)r[9 + k] * 31264u + r[k];
-        c += (uint64_t)r[8 + k] << 8;
+        uint64_t t = L[k] + (uint64_t)H[k] * 31264u;
+        t += (uint64_t)H[k - 1] * 256u;
+        c += t;
         o.v[k] = (uint32_t)c & BP_M29;
         c >>= 29;
     }
-    c += (uint64_t)r[17] << 8;  // weight 2^261
-    // E = everything at or above 2^256
-    uint64_t E = (uint64_t)(o.v[8] >> 24) + (c << 5);
+    // E = everything at or above 2^256: bits 24.. of limb 8, the carry out of limb 8 (weight 2^261),
+    // and 256*H[8] (weight 2^261 as well)
+    uint64_t E = (uint64_t)(o.v[8] >> 24) + ((c + ((uint64_t)H[8] << 8)) << 5);
     o.v[8] &= 0x00FFFFFFu;
     c = (uint64_t)o.v[0] + E * BP_P_C0;
     o.v[0] = (uint32_t)c & BP_M29;
@@ -175,45 +182,62 @@ BP_HD fp fp_fold18(const uint32_t r[18]) {
     return o;
 }
 
-// 9x9 product scanning: each column is one 64-bit accumulator fed by v_mad_u64_u32; 81 MADs.
+// 9x9 product scanning: each column is one 64-bit accumulator fed by v_mad_u64_u32; 81 MADs + 17 in the fold.
 BP_HD_MUL fp fp_mul(fp a, fp b) {
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         BP_OPAQUE(a.v[i]);
         BP_OPAQUE(b.v[i]);
     }
-    uint32_t r[18];
+    uint64_t L[9];
+    uint32_t H[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i <= k; i++) c += (uint64_t)a.v[i] * b.v[k - i];
+        L[k] = c;
+    }
     uint64_t c = 0;
 #pragma unroll
-    for (int k = 0; k < 17; k++) {
+    for (int k = 9; k < 17; k++) {
 #pragma unroll
-        for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++) c += (uint64_t)a.v[i] * b.v[k - i];
-        r[k] = (uint32_t)c & BP_M29;
+        for (int i = k - 8; i <= 8; i++) c += (uint64_t)a.v[i] * b.v[k - i];
+        H[k - 9] = (uint32_t)c & BP_M29;
         c >>= 29;
     }
-    r[17] = (uint32_t)c;
-    return fp_fold18(r);
+    H[8] = (uint32_t)c;
+    return fp_fold_cols(L, H);
 }
 
-// Squaring: 45 MADs (off-diagonal terms use a doubled operand).
+// Squaring: 45 MADs (off-diagonal terms use a doubled operand) + 17 in the fold.
 BP_HD_MUL fp fp_sqr(fp a) {
 #pragma unroll
     for (int i = 0; i < 9; i++) BP_OPAQUE(a.v[i]);
     uint32_t d[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
-    uint32_t r[18];
+    uint64_t L[9];
+    uint32_t H[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) c += (uint64_t)d[i] * a.v[k - i];
+        if ((k & 1) == 0) c += (uint64_t)a.v[k / 2] * a.v[k / 2];
+        L[k] = c;
+    }
     uint64_t c = 0;
 #pragma unroll
-    for (int k = 0; k < 17; k++) {
+    for (int k = 9; k < 17; k++) {
 #pragma unroll
-        for (int i = (k > 8 ? k - 8 : 0); 2 * i < k; i++) c += (uint64_t)d[i] * a.v[k - i];
+        for (int i = k - 8; 2 * i < k; i++) c += (uint64_t)d[i] * a.v[k - i];
         if ((k & 1) == 0) c += (uint64_t)a.v[k / 2] * a.v[k / 2];
-        r[k] = (uint32_t)c & BP_M29;
+        H[k - 9] = (uint32_t)c & BP_M29;
         c >>= 29;
     }
-    r[17] = (uint32_t)c;
-    return fp_fold18(r);
+    H[8] = (uint32_t)c;
+    return fp_fold_cols(L, H);
 }
 
 BP_HD fp fp_sqr_n(fp a, int n) {

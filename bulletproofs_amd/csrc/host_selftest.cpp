@@ -65,6 +65,11 @@ void bpt_ec_mul_glv(uint8_t* out, const uint8_t* a, const uint8_t* k) {
     xyzz r = ec_mul_glv(affine_from_be64(a), fq_from_be_reduce(k), tab);
     affine_to_be64(out, xyzz_to_affine(r));
 }
+// 2^(k+1) * a: one XYZZ doubling (so ZZ != 1) followed by the Jacobian k-fold doubling chain
+void bpt_ec_dbl_n(uint8_t* out, const uint8_t* a, int k) {
+    xyzz r = xyzz_dbl(xyzz_from_affine(affine_from_be64(a)));
+    affine_to_be64(out, xyzz_to_affine(xyzz_dbl_n(r, k)));
+}
 int bpt_ec_decompress(uint8_t* out, const uint8_t* in33) {
     affine p;
     if (!affine_decompress(p, in33)) return -1;

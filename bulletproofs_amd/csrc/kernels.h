@@ -14,11 +14,26 @@ size_t msm_slice_lds_bytes(int c, int M, int T);
 hipError_t launch_ingest_points(const uint8_t* in_be, affine_mem* out, size_t n, int* err, hipStream_t st);
 hipError_t launch_export_points(const affine_mem* in, uint8_t* out_be, size_t n, hipStream_t st);
 hipError_t launch_scalars_to_digits(const uint8_t* scalars_be, size_t n, size_t npad, int c, int W, int16_t* digits, hipStream_t st);
-hipError_t launch_msm_slice(const affine_mem* pts, const int16_t* digits, size_t n, size_t npad, int M, int c, int W, int S, int T, xyzz* partial,
-                            hipStream_t st);
+hipError_t launch_glv_expand(const affine_mem* in, affine_mem* lam, size_t n, hipStream_t st);
+hipError_t launch_glv_digits(const uint8_t* scalars_be, size_t n, size_t npad, int c, int W, int16_t* digits, hipStream_t st);
+hipError_t launch_msm_slice(const affine_mem* pts, const affine_mem* lam, size_t n1, const int16_t* digits, size_t n, size_t npad, int M, int c,
+                            int W, int S, int T, xyzz* partial, hipStream_t st);
 hipError_t launch_msm_reduce_slices(const xyzz* partial, int S, int W, xyzz* wsum, hipStream_t st);
 hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine_mem* init, affine_mem* out_limbs, uint8_t* out_be, hipStream_t st);
 
+
+// msm_sorted.hip: large-N path (global counting sort by bucket, balanced segment accumulation)
+struct SortedPlan {
+    int c, W, NB, CH, nchunks, L, nseg, lo_bits;
+    size_t npad;
+};
+struct SortedBufs {
+    uint32_t *cnt, *bstart, *ent, *queue;
+    uint16_t* bkt;
+    xyzz *Bk, *Pseg, *RC;
+};
+hipError_t launch_msm_sorted(const affine_mem* pts, const affine_mem* lam, size_t n1, const int16_t* digits, size_t n2, const SortedPlan& pl,
+                             const SortedBufs& b, xyzz* wsum, hipStream_t st);
 
 // gens_kernels.hip
 hipError_t launch_gens_bases(const affine_mem* pts, int np, int c, int W, xyzz* bases, hipStream_t st);

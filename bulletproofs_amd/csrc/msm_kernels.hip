@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ec.h"
+#include "ecmul.h"
 #include "fq.h"
 #include "kernels.h"
 
@@ -53,7 +54,7 @@ __global__ void k_export_points(const affine_mem* __restrict__ in, uint8_t* __re
 // ---------------------------------------------------------------------------------------------
 // scalars (32 B big-endian, any 256-bit value; reduced mod q like `Scalar::from(&BigInt)`) ->
 // signed c-bit digits d_w in [-(2^(c-1)-1), 2^(c-1)], W = 256/c + 1 windows, window-major.
-__device__ __forceinline__ void recode_signed(const uint32_t k[8], int c, int W, int16_t* __restrict__ out, size_t stride) {
+__device__ __forceinline__ void recode_signed(const uint32_t k[8], int c, int W, bool negate, int16_t* __restrict__ out, size_t stride) {
     uint32_t carry = 0;
     const uint32_t half = 1u << (c - 1);
     const uint32_t mask = (1u << c) - 1;
@@ -75,7 +76,7 @@ __device__ __forceinline__ void recode_signed(const uint32_t k[8], int c, int W,
             d = (int)v;
             carry = 0;
         }
-        out[(size_t)w * stride] = (int16_t)d;
+        out[(size_t)w * stride] = (int16_t)(negate ? -d : d);
     }
 }
 
@@ -91,7 +92,42 @@ __global__ void k_scalars_to_digits(const uint8_t* __restrict__ scalars_be, size
 #pragma unroll
     for (int j = 0; j < 8; j++) k.v[j] = __builtin_bswap32(src[7 - j]);
     fq_final_reduce(k.v, 0);
-    recode_signed(k.v, c, W, digits + i, npad);
+    recode_signed(k.v, c, W, false, digits + i, npad);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GLV front end of every MSM: k*P = k1*P + k2*lambda(P) with |k1|, |k2| < 2^129 and
+// lambda(x, y) = (beta*x, y).  An n-term MSM over 256-bit scalars becomes a 2n-term MSM over
+// 129-bit scalars: the same number of bucket additions, but half the windows, so the serial
+// doubling chain of the final Horner step (one lane, latency-bound) is 128 instead of 256 long.
+// Virtual point v < n is points[v], v >= n is lam[v - n].
+__global__ void k_glv_expand(const affine_mem* __restrict__ in, affine_mem* __restrict__ lam, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    affine_mem m = in[i];
+    if (!affine_mem_is_inf(m)) m.x = fp_to_words(fp_mul(fp_from_words(m.x), fp_beta()));
+    lam[i] = m;
+}
+
+// digits [W][npad] over the 2n virtual points (columns [2n, npad) zero); sign of k1 / k2 folded in.
+__global__ void k_glv_digits(const uint8_t* __restrict__ scalars_be, size_t n, size_t npad, int c, int W, int16_t* __restrict__ digits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    if (i >= 2 * n) {
+        for (int w = 0; w < W; w++) digits[(size_t)w * npad + i] = 0;
+        return;
+    }
+    if (i >= n) return;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(scalars_be + 32 * i);
+    fq k;
+#pragma unroll
+    for (int j = 0; j < 8; j++) k.v[j] = __builtin_bswap32(src[7 - j]);
+    fq_final_reduce(k.v, 0);
+    fq k1, k2;
+    bool n1, n2;
+    fq_glv_split(k, k1, n1, k2, n2);
+    recode_signed(k1.v, c, W, n1, digits + i, npad);
+    recode_signed(k2.v, c, W, n2, digits + n + i, npad);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -105,8 +141,9 @@ __global__ void k_scalars_to_digits(const uint8_t* __restrict__ scalars_be, size
 //      Hillis-Steele suffix scan followed by a tree reduction (r is a power of two -> doublings).
 // LDS: 2*(NB+1) u32 + M u16 + T XYZZ.
 template <int T>
-__global__ __launch_bounds__(T) void k_msm_slice(const affine_mem* __restrict__ pts, const int16_t* __restrict__ digits, size_t n, size_t npad,
-                                                 int M, int c, xyzz* __restrict__ partial /* [W][S] */) {
+__global__ __launch_bounds__(T) void k_msm_slice(const affine_mem* __restrict__ pts, const affine_mem* __restrict__ lam, size_t n1,
+                                                 const int16_t* __restrict__ digits, size_t n, size_t npad, int M, int c,
+                                                 xyzz* __restrict__ partial /* [W][S] */) {
     extern __shared__ __align__(16) uint8_t smem_raw[];
     const int NB = 1 << (c - 1);
     xyzz* red = reinterpret_cast<xyzz*>(smem_raw);                   // T
@@ -173,7 +210,8 @@ __global__ __launch_bounds__(T) void k_msm_slice(const affine_mem* __restrict__ 
             uint32_t j0 = start[b], j1 = start[b + 1];
             for (uint32_t j = j0; j < j1; j++) {
                 uint32_t e = sorted[j];
-                affine p = affine_load(pts[base + (e & 0x7fff)]);
+                size_t v = base + (e & 0x7fff);
+                affine p = affine_load(v < n1 ? pts[v] : lam[v - n1]);
                 if (e & 0x8000) p.y = fp_neg(p.y);
                 xyzz_madd(B, p);
             }
@@ -222,9 +260,9 @@ __global__ __launch_bounds__(T) void k_msm_slice(const affine_mem* __restrict__ 
     if (tid == 0) partial[(size_t)w * S + slice] = red[0];
 }
 
-template __global__ void k_msm_slice<64>(const affine_mem*, const int16_t*, size_t, size_t, int, int, xyzz*);
-template __global__ void k_msm_slice<128>(const affine_mem*, const int16_t*, size_t, size_t, int, int, xyzz*);
-template __global__ void k_msm_slice<256>(const affine_mem*, const int16_t*, size_t, size_t, int, int, xyzz*);
+template __global__ void k_msm_slice<64>(const affine_mem*, const affine_mem*, size_t, const int16_t*, size_t, size_t, int, int, xyzz*);
+template __global__ void k_msm_slice<128>(const affine_mem*, const affine_mem*, size_t, const int16_t*, size_t, size_t, int, int, xyzz*);
+template __global__ void k_msm_slice<256>(const affine_mem*, const affine_mem*, size_t, const int16_t*, size_t, size_t, int, int, xyzz*);
 
 // ---------------------------------------------------------------------------------------------
 // wsum[w] = sum over slices of partial[w][s]; one 64-lane workgroup per window.
@@ -257,7 +295,7 @@ __global__ void k_msm_horner(const xyzz* __restrict__ wsum, int W, int c, const 
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     xyzz acc = wsum[W - 1];
     for (int w = W - 2; w >= 0; w--) {
-        for (int k = 0; k < c; k++) acc = xyzz_dbl(acc);
+        acc = xyzz_dbl_n(acc, c);
         xyzz o = wsum[w];
         xyzz_add(acc, o);
     }
@@ -291,20 +329,29 @@ hipError_t launch_export_points(const affine_mem* in, uint8_t* out_be, size_t n,
     hipLaunchKernelGGL(k_export_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out_be, n);
     return hipGetLastError();
 }
+hipError_t launch_glv_expand(const affine_mem* in, affine_mem* lam, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_glv_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, lam, n);
+    return hipGetLastError();
+}
+hipError_t launch_glv_digits(const uint8_t* scalars_be, size_t n, size_t npad, int c, int W, int16_t* digits, hipStream_t st) {
+    hipLaunchKernelGGL(k_glv_digits, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st, scalars_be, n, npad, c, W, digits);
+    return hipGetLastError();
+}
 hipError_t launch_scalars_to_digits(const uint8_t* scalars_be, size_t n, size_t npad, int c, int W, int16_t* digits, hipStream_t st) {
     hipLaunchKernelGGL(k_scalars_to_digits, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st, scalars_be, n, npad, c, W, digits);
     return hipGetLastError();
 }
-hipError_t launch_msm_slice(const affine_mem* pts, const int16_t* digits, size_t n, size_t npad, int M, int c, int W, int S, int T, xyzz* partial,
-                            hipStream_t st) {
+hipError_t launch_msm_slice(const affine_mem* pts, const affine_mem* lam, size_t n1, const int16_t* digits, size_t n, size_t npad, int M, int c,
+                            int W, int S, int T, xyzz* partial, hipStream_t st) {
     size_t lds = msm_slice_lds_bytes(c, M, T);
     dim3 grid((unsigned)S, (unsigned)W);
     if (T == 64)
-        hipLaunchKernelGGL(k_msm_slice<64>, grid, dim3(64), lds, st, pts, digits, n, npad, M, c, partial);
+        hipLaunchKernelGGL(k_msm_slice<64>, grid, dim3(64), lds, st, pts, lam, n1, digits, n, npad, M, c, partial);
     else if (T == 128)
-        hipLaunchKernelGGL(k_msm_slice<128>, grid, dim3(128), lds, st, pts, digits, n, npad, M, c, partial);
+        hipLaunchKernelGGL(k_msm_slice<128>, grid, dim3(128), lds, st, pts, lam, n1, digits, n, npad, M, c, partial);
     else
-        hipLaunchKernelGGL(k_msm_slice<256>, grid, dim3(256), lds, st, pts, digits, n, npad, M, c, partial);
+        hipLaunchKernelGGL(k_msm_slice<256>, grid, dim3(256), lds, st, pts, lam, n1, digits, n, npad, M, c, partial);
     return hipGetLastError();
 }
 hipError_t launch_msm_reduce_slices(const xyzz* partial, int S, int W, xyzz* wsum, hipStream_t st) {

@@ -67,6 +67,9 @@ int bp_msm_device(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be
 
 /* Testing / tuning knob: force the Pippenger window width (0 = automatic). */
 void bp_msm_set_window(bp_ctx* ctx, int c);
+/* Testing / tuning knob: 0 = automatic, 1 = LDS slice path (small / medium n), 2 = global sorted
+ * path (large n).  Both compute the same sum; results are identical. */
+void bp_msm_set_path(bp_ctx* ctx, int path);
 
 /* bp_gens — the shared generators g_vec[nm], h_vec[nm], G, H that the reference passes to every
  * prove/verify call as slices (range_proof.rs:46-49, 267-270, 539-542; StatementRP,

@@ -64,6 +64,44 @@ def test_msm_all_window_widths(ctx, oracle_c, c):
         ctx.set_window(0)
 
 
+@pytest.mark.parametrize("c,n", [(2, 5), (3, 40), (6, 300), (9, 1000), (12, 3000), (15, 3000), (0, 1)])
+def test_msm_sorted_path_matches_oracle(ctx, oracle_c, c, n):
+    """The large-N path (global counting sort + balanced segment accumulation, msm_sorted.hip) forced at
+    sizes the oracle finishes: every window width class, ragged last segments, single point."""
+    rng = random.Random(3000 + 16 * c + n)
+    pts = _rand_points(rng, n, oracle_c)
+    ks = [rng.randrange(ec.Q) for _ in range(n)]
+    init = oracle_c.mul(ec.G, 31337)
+    want = ec.enc64(oracle_c.msm_naive(pts, ks, init))
+    ctx.set_path(2)
+    ctx.set_window(c)
+    try:
+        assert ctx.msm(*_pack(pts, ks), ec.enc64(init)) == want
+    finally:
+        ctx.set_window(0)
+        ctx.set_path(0)
+
+
+def test_msm_sorted_path_skewed_buckets(ctx, oracle_c):
+    """Bucket sizes far from uniform: the +-1 / 0 / small scalars of the prover's A commitment
+    (range_proof.rs:93-107), repeated and opposite points, infinity, and buckets spanning many segments."""
+    rng = random.Random(77)
+    base = _rand_points(rng, 16, oracle_c)
+    n = 2500
+    pts = [base[rng.randrange(16)] for _ in range(n)]
+    pts[7] = None
+    pts[8] = ec.neg(pts[9])
+    ks = [rng.choice([0, 1, ec.Q - 1, 2, 3, 1 << 128, ec.Q - (1 << 128)]) for _ in range(n)]
+    ks[9] = ks[8] = 5
+    want = ec.enc64(oracle_c.msm_naive(pts, ks, None))
+    for path in (1, 2):
+        ctx.set_path(path)
+        try:
+            assert ctx.msm(*_pack(pts, ks), None) == want, path
+        finally:
+            ctx.set_path(0)
+
+
 def test_msm_rejects_off_curve_point(ctx):
     import bulletproofs_amd as bpa
     bad = (1).to_bytes(32, "big") + (1).to_bytes(32, "big")
@@ -83,6 +121,30 @@ def test_msm_linearity_large(ctx, oracle_c):
     pts = [base[i] for i in idx]
     a = [rng.randrange(ec.Q) for _ in range(n)]
     pb, sb = _pack(pts, a)
-    got = ctx.msm(pb, sb, None)
     want_scalar = sum(a[i] * rs[idx[i]] for i in range(n)) % ec.Q
-    assert got == ec.enc64(oracle_c.mul(ec.G, want_scalar))
+    want = ec.enc64(oracle_c.mul(ec.G, want_scalar))
+    assert ctx.msm(pb, sb, None) == want          # automatic path (sorted at this size)
+    for path in (1, 2):
+        ctx.set_path(path)
+        try:
+            assert ctx.msm(pb, sb, None) == want, path
+        finally:
+            ctx.set_path(0)
+
+
+def test_msm_full_size_2pow20(ctx, oracle_c):
+    """BASELINE.json configs[4] size (2^20 terms): sum k_i (r_i G) == (sum k_i r_i) G with 2^20 distinct
+    points r_i G made on the GPU (fixed-base batch) and independent 256-bit scalars."""
+    import numpy as np
+    n = 1 << 20
+    rng = np.random.default_rng(2020)
+    rb = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    kb = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    rb[:, 0] &= 0x7F  # r_i < 2^255 < q: no reduction needed on the checking side
+    pts = b"".join(ctx.fixed_base_mul_batch(rb[i:i + 65536].tobytes()) for i in range(0, n, 65536))
+    got = ctx.msm(pts, kb.tobytes(), None)
+    acc = 0
+    rbb, kbb = rb.tobytes(), kb.tobytes()
+    for i in range(n):
+        acc += int.from_bytes(rbb[32 * i:32 * i + 32], "big") * int.from_bytes(kbb[32 * i:32 * i + 32], "big")
+    assert got == ec.enc64(oracle_c.mul(ec.G, acc % ec.Q))

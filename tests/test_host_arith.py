@@ -88,6 +88,11 @@ def test_ec(L, oracle_c):
         o = ctypes.create_string_buffer(64)
         assert L.bpt_ec_decompress(o, ec.compress(a)) == 0 and ec.dec64(o.raw) == a
         assert L.bpt_ec_on_curve(ec.enc64(a)) == 1
+    for a in pts[:3]:
+        for k in (0, 1, 2, 3, 5, 15, 40):
+            o = ctypes.create_string_buffer(64)
+            L.bpt_ec_dbl_n(o, ec.enc64(a), k)
+            assert ec.dec64(o.raw) == oracle_c.mul(a, 1 << (k + 1)), k
     assert p2(L.bpt_ec_madd, None, pts[0]) == pts[0]
     assert p2(L.bpt_ec_mul, pts[0], b32(Q)) is None
     a = pts[0]
