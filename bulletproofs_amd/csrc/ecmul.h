@@ -79,4 +79,64 @@ BP_HD xyzz ec_mul_glv(const affine& P, const fq& k, xyzz* tab) {
     return acc;
 }
 
+// Interleaved (Straus) form for several points in ONE lane: sum_j k_j * P_j with a single chain of
+// 128 doublings shared by all of them (each extra point costs only its 66 window additions).  Used by
+// the batched verifier when a lane owns more than one proof-specific point.
+//   loadP(j) -> affine, loadK(j) -> fq   for j < cnt <= PPL
+//   tab: PPL * ECMUL_NT lane-private XYZZ entries, dig: PPL * ECMUL_DIGB lane-private bytes.
+// The doubling chain runs through Jacobian coordinates (xyzz_dbl_n: 2M + 5S per doubling).
+#define ECMUL_DIGB 72  // signed digits of k1 at [0, 33), of k2 at [36, 69)
+template <int PPL, class LoadP, class LoadK>
+BP_HD xyzz ec_mul_glv_multi(LoadP loadP, LoadK loadK, int cnt, xyzz* tab, int8_t* dig) {
+    for (int j = 0; j < cnt; j++) {
+        affine P = loadP(j);
+        int8_t* dj = dig + j * ECMUL_DIGB;
+        if (affine_is_inf(P)) {
+            for (int w = 0; w < ECMUL_DIGB; w++) dj[w] = 0;
+            continue;
+        }
+        xyzz* tj = tab + j * ECMUL_NT;
+        xyzz t = xyzz_from_affine(P);
+        tj[0] = t;
+        t = xyzz_dbl_affine(P);
+        tj[1] = t;
+        for (int i = 2; i < ECMUL_NT; i++) {
+            xyzz_madd(t, P);
+            tj[i] = t;
+        }
+        fq k1, k2;
+        bool n1, n2;
+        fq_glv_split(loadK(j), k1, n1, k2, n2);
+        const uint64_t c1 = ecmul_carry_mask(k1), c2 = ecmul_carry_mask(k2);
+        for (int w = 0; w < ECMUL_WINS; w++) {
+            int d1 = ecmul_digit(k1, c1, w), d2 = ecmul_digit(k2, c2, w);
+            dj[w] = (int8_t)(n1 ? -d1 : d1);
+            dj[36 + w] = (int8_t)(n2 ? -d2 : d2);
+        }
+    }
+    const fp beta = fp_beta();
+    xyzz acc = xyzz_inf();
+    for (int w = ECMUL_WINS - 1; w >= 0; w--) {
+        if (w != ECMUL_WINS - 1) acc = xyzz_dbl_n(acc, 4);
+        for (int j = 0; j < cnt; j++) {
+            const int8_t* dj = dig + j * ECMUL_DIGB;
+            const xyzz* tj = tab + j * ECMUL_NT;
+            int d1 = dj[w];
+            if (d1 != 0) {
+                xyzz e = tj[(d1 < 0 ? -d1 : d1) - 1];
+                if (d1 < 0) e.Y = fp_neg(e.Y);
+                xyzz_add(acc, e);
+            }
+            int d2 = dj[36 + w];
+            if (d2 != 0) {
+                xyzz e = tj[(d2 < 0 ? -d2 : d2) - 1];
+                e.X = fp_mul(e.X, beta);
+                if (d2 < 0) e.Y = fp_neg(e.Y);
+                xyzz_add(acc, e);
+            }
+        }
+    }
+    return acc;
+}
+
 }  // namespace bp

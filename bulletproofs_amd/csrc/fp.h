@@ -144,30 +144,11 @@ BP_HD fp fp_neg(const fp& a) { return fp_sub(fp_zero(), a); }
 BP_HD fp fp_dbl(const fp& a) { return fp_add(a, a); }
 BP_HD bool fp_eq(const fp& a, const fp& b) { return fp_is_zero(fp_sub(a, b)); }
 
-// Reduce a 9x9 product given as
-//   L[0..8]  the low columns, each a raw 64-bit sum of <= 9 products (< 2^61.2, NOT carry-propagated),
-//   H[0..8]  the high columns 9..17 carry-propagated to 29-bit limbs (H[8], the final carry, < 2^21),
-// modulo p.  2^261 = 2^5 (2^32 + 977) = 256 * 2^29 + 31264 (mod p), so high limb H[k] (weight
-// 2^261 * 2^(29k)) adds 31264*H[k] to column k and 256*H[k] to column k+1: two more MADs per column
-// with the low column as the addend, then ONE carry pass over the nine sums.  (Carry-propagating
-// the low columns first, as a textbook product scan does, costs an and + 64-bit shift + 64-bit add
-// per column for nothing: only the high half has to be split into 29-bit multiplier operands.)
-BP_HD fp fp_fold_cols(const uint64_t L[9], const uint32_t H[9]) {
-    fp o;
-    uint64_t c = L[0] + (uint64_t)H[0] * 31264u;
-    o.v[0] = (uint32_t)c & BP_M29;
-    c >>= 29;
-#pragma unroll
-    for (int k = 1; k < 9; k++) {
-        uint64_t t = L[k] + (uint64_t)H[k] * 31264u;
-        t += (uint64_t)H[k - 1] * 256u;
-        c += t;
-        o.v[k] = (uint32_t)c & BP_M29;
-        c >>= 29;
-    }
-    // E = everything at or above 2^256: bits 24.. of limb 8, the carry out of limb 8 (weight 2^261),
-    // and 256*H[8] (weight 2^261 as well)
-    uint64_t E = (uint64_t)(o.v[8] >> 24) + ((c + ((uint64_t)H[8] << 8)) << 5);
+// Tail of a product: o.v[0..8] hold the nine output limbs after one carry pass, c the carry out of
+// limb 8 (weight 2^261) and h8 the top high limb (weight 2^261 * 2^(29*8), folded once already so it
+// arrives here as 256*h8 at weight 2^261).  Folds everything at or above 2^256 with 2^256 = 2^32 + 977.
+BP_HD void fp_fold_top(fp& o, uint64_t c, uint32_t h8) {
+    uint64_t E = (uint64_t)(o.v[8] >> 24) + ((c + ((uint64_t)h8 << 8)) << 5);
     o.v[8] &= 0x00FFFFFFu;
     c = (uint64_t)o.v[0] + E * BP_P_C0;
     o.v[0] = (uint32_t)c & BP_M29;
@@ -179,25 +160,24 @@ BP_HD fp fp_fold_cols(const uint64_t L[9], const uint32_t H[9]) {
     o.v[2] = (uint32_t)c & BP_M29;
     c >>= 29;
     o.v[3] += (uint32_t)c;
-    return o;
 }
 
-// 9x9 product scanning: each column is one 64-bit accumulator fed by v_mad_u64_u32; 81 MADs + 17 in the fold.
+// 9x9 product scanning on v_mad_u64_u32.  The HIGH columns 9..16 are accumulated first and split
+// into 29-bit limbs H[k] (they must become multiplier operands).  2^261 = 256 * 2^29 + 31264 (mod p),
+// so H[k] (weight 2^261 * 2^(29k)) adds 31264*H[k] to column k and 256*H[k] to column k+1: each LOW
+// column is then ONE accumulator chain  carry + sum a_i b_(k-i) + 31264 H[k] + 256 H[k-1]  followed
+// by a mask and a shift - no separate carry pass over the low half, no 64-bit additions at all.
+// 81 + 17 MADs.  (The multiplication by 256 goes through the multiplier on purpose: as a 64-bit
+// shift-and-add it costs two instructions and a register pair with a zeroed high half.)
 BP_HD_MUL fp fp_mul(fp a, fp b) {
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         BP_OPAQUE(a.v[i]);
         BP_OPAQUE(b.v[i]);
     }
-    uint64_t L[9];
+    uint32_t k256 = 256u;
+    BP_OPAQUE(k256);
     uint32_t H[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int i = 0; i <= k; i++) c += (uint64_t)a.v[i] * b.v[k - i];
-        L[k] = c;
-    }
     uint64_t c = 0;
 #pragma unroll
     for (int k = 9; k < 17; k++) {
@@ -207,26 +187,31 @@ BP_HD_MUL fp fp_mul(fp a, fp b) {
         c >>= 29;
     }
     H[8] = (uint32_t)c;
-    return fp_fold_cols(L, H);
+    fp o;
+    c = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) c += (uint64_t)a.v[i] * b.v[k - i];
+        c += (uint64_t)H[k] * 31264u;
+        if (k > 0) c += (uint64_t)H[k - 1] * k256;
+        o.v[k] = (uint32_t)c & BP_M29;
+        c >>= 29;
+    }
+    fp_fold_top(o, c, H[8]);
+    return o;
 }
 
 // Squaring: 45 MADs (off-diagonal terms use a doubled operand) + 17 in the fold.
 BP_HD_MUL fp fp_sqr(fp a) {
 #pragma unroll
     for (int i = 0; i < 9; i++) BP_OPAQUE(a.v[i]);
+    uint32_t k256 = 256u;
+    BP_OPAQUE(k256);
     uint32_t d[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
-    uint64_t L[9];
     uint32_t H[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int i = 0; 2 * i < k; i++) c += (uint64_t)d[i] * a.v[k - i];
-        if ((k & 1) == 0) c += (uint64_t)a.v[k / 2] * a.v[k / 2];
-        L[k] = c;
-    }
     uint64_t c = 0;
 #pragma unroll
     for (int k = 9; k < 17; k++) {
@@ -237,7 +222,20 @@ BP_HD_MUL fp fp_sqr(fp a) {
         c >>= 29;
     }
     H[8] = (uint32_t)c;
-    return fp_fold_cols(L, H);
+    fp o;
+    c = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) c += (uint64_t)d[i] * a.v[k - i];
+        if ((k & 1) == 0) c += (uint64_t)a.v[k / 2] * a.v[k / 2];
+        c += (uint64_t)H[k] * 31264u;
+        if (k > 0) c += (uint64_t)H[k - 1] * k256;
+        o.v[k] = (uint32_t)c & BP_M29;
+        c >>= 29;
+    }
+    fp_fold_top(o, c, H[8]);
+    return o;
 }
 
 BP_HD fp fp_sqr_n(fp a, int n) {

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void k_srt_acc(const affine_mem* __restrict
 // Buckets with at most SRT_BIG segment partials are summed by their own lane; larger ones (skewed
 // digit distributions: the short top window, +-1 / small scalars) are queued for k_srt_finalize_big
 // so that no lane runs a long serial chain of additions.
-#define SRT_BIG 6
+#define SRT_BIG 16
 __global__ __launch_bounds__(256, 2) void k_srt_finalize(const uint32_t* __restrict__ bstart, int NB, int L, int nseg, int W,
                                                          xyzz* __restrict__ Bk, const xyzz* __restrict__ Pseg, uint32_t* __restrict__ queue) {
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -9,8 +9,9 @@
 //                      x_u*G (:571, :588) from the generator table, then the whole scalar vector of
 //                      :670-740 in Montgomery arithmetic mod q, recoded to signed window digits.
 //   k_bpv_msm        : TP lanes per proof.  The MSM of :742-774: fixed generators via table gathers
-//                      (no doublings), proof-specific points (S, L_j, R_j, V_j, T1, T2) via NAF
-//                      double-and-add, lane-tree reduction, and the comparison with A (:777).
+//                      (no doublings), proof-specific points (S, L_j, R_j, V_j, T1, T2) via GLV +
+//                      interleaved 4-bit windows (ecmul.h: lanes that own several points share one
+//                      doubling chain), lane-tree reduction, and the comparison with A (:777).
 //
 // Per-proof verdicts follow `Result<(), Errors>`: 0 = Ok, 3 = RangeProofError, 255 = the proof bytes
 // would not deserialize in the reference (bad point / scalar >= q / zero challenge).
@@ -60,12 +61,13 @@ __global__ void k_bpv_decompress(const uint8_t* __restrict__ proofs, size_t proo
 #define BPV_MSM_WAVES 2
 #endif
 
-// TP lanes per proof; 256-thread workgroups.
-template <int TP>
+// TP lanes per proof, PPL proof-specific points per lane and pass (one shared doubling chain per
+// lane: the fewer lanes a proof has, the fewer chains it pays for); 256-thread workgroups.
+template <int TP, int PPL>
 __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int m, int k, size_t nproofs, const affine_mem* __restrict__ pts,
                                                  const affine_mem* __restrict__ table, int c, int W, const int16_t* __restrict__ digF,
-                                                 const fq* __restrict__ varS, xyzz* __restrict__ vartab, const int* __restrict__ bad,
-                                                 uint8_t* __restrict__ verdicts, int dbg_skip) {
+                                                 const fq* __restrict__ varS, xyzz* __restrict__ vartab, int8_t* __restrict__ vardig,
+                                                 const int* __restrict__ bad, uint8_t* __restrict__ verdicts, int dbg_skip) {
     __shared__ xyzz red[256];
     const int tid = threadIdx.x;
     const int lane = tid % TP;
@@ -89,10 +91,20 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
         }
         const affine_mem* P = pts + pr * NPT;
         const fq* vs = varS + pr * (size_t)NV;
-        for (int v = lane; v < ((dbg_skip & 2) ? 0 : NV); v += TP) {
+        const size_t gl = (size_t)blockIdx.x * 256 + tid;
+        xyzz* tab = vartab + gl * (PPL * ECMUL_NT);
+        int8_t* dig = vardig + gl * (PPL * ECMUL_DIGB);
+        for (int v0 = lane; v0 < ((dbg_skip & 2) ? 0 : NV); v0 += TP * PPL) {
+            int cnt = (NV - v0 + TP - 1) / TP;
+            if (cnt > PPL) cnt = PPL;
             // variable point order: S, L_0.., R_0.., V_0.., T1, T2  ->  index into pts
-            int pi = (v == 0) ? 1 : (v < 1 + 2 * k + m) ? (3 + v) : (v == 1 + 2 * k + m ? 2 : 3);
-            xyzz t = ec_mul_glv(affine_load(P[pi]), vs[v], vartab + ((size_t)blockIdx.x * 256 + tid) * ECMUL_NT);
+            auto loadP = [&](int j) {
+                int v = v0 + TP * j;
+                int pi = (v == 0) ? 1 : (v < 1 + 2 * k + m) ? (3 + v) : (v == 1 + 2 * k + m ? 2 : 3);
+                return affine_load(P[pi]);
+            };
+            auto loadK = [&](int j) { return vs[v0 + TP * j]; };
+            xyzz t = ec_mul_glv_multi<PPL>(loadP, loadK, cnt, tab, dig);
             xyzz_add(acc, t);
         }
     }
@@ -129,21 +141,32 @@ hipError_t launch_bpv_decompress(const uint8_t* proofs, size_t proof_len, const 
                        bad);
     return hipGetLastError();
 }
+// lanes per proof -> proof-specific points per lane and pass
+static int bpv_ppl(int tp) { return tp == 4 ? 4 : (tp == 8 ? 2 : 1); }
 size_t bpv_msm_vartab_bytes(int tp, size_t nproofs) {
     size_t blocks = (nproofs + (256 / tp) - 1) / (256 / tp);
-    return blocks * 256 * ECMUL_NT * sizeof(xyzz);
+    return blocks * 256 * bpv_ppl(tp) * (ECMUL_NT * sizeof(xyzz) + ECMUL_DIGB);
 }
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
                           const int16_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st) {
     unsigned blocks = (unsigned)((nproofs + (256 / tp) - 1) / (256 / tp));
     const char* e = getenv("BP_DEBUG_SKIP");  // timing experiments only: 1 = skip fixed part, 2 = skip variable part
     int dbg = e ? atoi(e) : 0;
-    if (tp == 16)
-        hipLaunchKernelGGL(k_bpv_msm<16>, dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, bad, verdicts, dbg);
+    int8_t* vardig = reinterpret_cast<int8_t*>(vartab + (size_t)blocks * 256 * bpv_ppl(tp) * ECMUL_NT);
+#define BPV_LAUNCH(TP, PPL)                                                                                                                  \
+    hipLaunchKernelGGL((k_bpv_msm<TP, PPL>), dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, vardig, \
+                       bad, verdicts, dbg)
+    if (tp == 4)
+        BPV_LAUNCH(4, 4);
+    else if (tp == 8)
+        BPV_LAUNCH(8, 2);
+    else if (tp == 16)
+        BPV_LAUNCH(16, 1);
     else if (tp == 32)
-        hipLaunchKernelGGL(k_bpv_msm<32>, dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, bad, verdicts, dbg);
+        BPV_LAUNCH(32, 1);
     else
-        hipLaunchKernelGGL(k_bpv_msm<64>, dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, bad, verdicts, dbg);
+        BPV_LAUNCH(64, 1);
+#undef BPV_LAUNCH
     return hipGetLastError();
 }
 

@@ -97,7 +97,7 @@ int bp_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int
 int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
                                       const void* d_coms_xy, size_t nproofs, void* d_verdicts);
 int bp_ctx_sync(bp_ctx* ctx);
-/* Tuning knob: lanes per proof in the verifier's MSM kernel (16, 32 or 64; 0 = default). */
+/* Tuning knob: lanes per proof in the verifier's MSM kernel (4, 8, 16, 32 or 64; 0 = chosen by batch size). */
 void bp_verify_set_lanes(bp_ctx* ctx, int lanes);
 
 /* bp_scalar_mul_batch — n independent out[i] = scalars[i] * points[i].

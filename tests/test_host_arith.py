@@ -93,6 +93,18 @@ def test_ec(L, oracle_c):
             o = ctypes.create_string_buffer(64)
             L.bpt_ec_dbl_n(o, ec.enc64(a), k)
             assert ec.dec64(o.raw) == oracle_c.mul(a, 1 << (k + 1)), k
+    for cnt in (1, 2, 3, 4):
+        ps = [pts[i] for i in range(cnt)]
+        if cnt == 3:
+            ps[1] = None  # infinity among the points
+        if cnt == 4:
+            ps[3] = ec.neg(ps[0])
+        ks = [rng.randrange(Q) for _ in range(cnt)]
+        if cnt == 4:
+            ks[3] = ks[0]  # k*P + k*(-P) cancels inside the shared accumulator
+        o = ctypes.create_string_buffer(64)
+        L.bpt_ec_mul_glv_multi(o, b"".join(ec.enc64(p) for p in ps), b"".join(b32(k) for k in ks), cnt)
+        assert ec.dec64(o.raw) == oracle_c.msm_naive(ps, ks, None), cnt
     assert p2(L.bpt_ec_madd, None, pts[0]) == pts[0]
     assert p2(L.bpt_ec_mul, pts[0], b32(Q)) is None
     a = pts[0]
