@@ -18,6 +18,7 @@ EXPORTED_SYMBOLS = [
     "bp_msm_device",
     "bp_msm_set_window",
     "bp_msm_set_path",
+    "bp_msm_batch",
     "bp_gens_create",
     "bp_gens_destroy",
     "bp_gens_table_bytes",
@@ -98,6 +99,8 @@ def lib():
     L.bp_fold_bases.restype = i32
     L.bp_fixed_base_mul_batch.argtypes = [vp, cp, sz, cp]
     L.bp_fixed_base_mul_batch.restype = i32
+    L.bp_msm_batch.argtypes = [vp, vp, vp, sz, cp]
+    L.bp_msm_batch.restype = i32
     L.bp_generate_bases.argtypes = [i32, ctypes.c_uint64, sz, sz, cp, cp, cp, cp]
     L.bp_generate_bases.restype = i32
     prove_args = [vp, vp, i32, cp, cp, i32, cp, sz, cp, sz, ctypes.POINTER(sz)]
@@ -123,6 +126,12 @@ def lib():
 def _check(rc):
     if rc != BP_OK:
         raise BpError(rc, lib().bp_last_error().decode(errors="replace"))
+
+
+class MsmJob(ctypes.Structure):
+    """`bp_msm_job` of include/bpmsm.h."""
+    _fields_ = [("gen_scalars_be", ctypes.c_void_p), ("extra_points_xy", ctypes.c_void_p), ("extra_scalars_be", ctypes.c_void_p),
+                ("n_extra", ctypes.c_size_t)]
 
 
 class Context:
@@ -214,6 +223,24 @@ class Context:
         n = len(lo_xy) // 64
         out = ctypes.create_string_buffer(max(64 * n, 1))
         _check(lib().bp_fold_bases(self._h, bytes(lo_xy), bytes(hi_xy), n, bytes(s_lo), bytes(s_hi), out))
+        return out.raw[:64 * n]
+
+    def msm_batch(self, gens, jobs):
+        """jobs: list of (gen_scalars_be or None, extra_points_xy, extra_scalars_be); returns 64 bytes per job."""
+        n = len(jobs)
+        arr = (MsmJob * max(n, 1))()
+        keep = []
+        for i, (gs, xp, xs) in enumerate(jobs):
+            xp, xs = bytes(xp or b""), bytes(xs or b"")
+            bufs = [ctypes.create_string_buffer(bytes(gs), len(gs)) if gs is not None else None,
+                    ctypes.create_string_buffer(xp, max(len(xp), 1)), ctypes.create_string_buffer(xs, max(len(xs), 1))]
+            keep.append(bufs)
+            arr[i].gen_scalars_be = ctypes.cast(bufs[0], ctypes.c_void_p) if bufs[0] is not None else None
+            arr[i].extra_points_xy = ctypes.cast(bufs[1], ctypes.c_void_p)
+            arr[i].extra_scalars_be = ctypes.cast(bufs[2], ctypes.c_void_p)
+            arr[i].n_extra = len(xp) // 64
+        out = ctypes.create_string_buffer(max(64 * n, 1))
+        _check(lib().bp_msm_batch(self._h, gens._h, ctypes.byref(arr), n, out))
         return out.raw[:64 * n]
 
     def fixed_base_mul_batch(self, scalars_be):

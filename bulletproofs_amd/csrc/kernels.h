@@ -55,6 +55,12 @@ hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, cons
 size_t bpv_msm_vartab_bytes(int tp, size_t nproofs);
 
 
+// msm_batch.hip
+hipError_t launch_mb_digits(const uint8_t* scalars_be, size_t total, int c, int W, int16_t* digits, hipStream_t st);
+size_t mb_vartab_bytes(size_t njobs);
+hipError_t launch_mb_msm(size_t njobs, int np, const affine_mem* table, int c, int W, const int16_t* digF, const uint8_t* has_gen,
+                         const affine_mem* xpts, const uint8_t* xsc_be, const uint32_t* xoff, xyzz* vartab, xyzz* out, hipStream_t st);
+
 // ecbatch_kernels.hip
 size_t ecbatch_vartab_bytes(size_t n);
 hipError_t launch_scalar_mul_batch(const affine_mem* pts, const uint8_t* scalars_be, size_t n, affine_mem* out, xyzz* vartab, hipStream_t st);

@@ -1,0 +1,113 @@
+// bp_msm_batch: many small MSMs that share the generator prefix - the shape of the
+// reference's fast verifiers when many statements are checked at once:
+//     out_j = sum_p gen_scalars[j][p] * gens[p]  +  sum_e extra_scalars[j][e] * extra_points[j][e]
+// (`InnerProductArg::fast_verify`, /root/reference/src/proofs/inner_product.rs:334-338;
+//  `RangeProof::aggregated_verify`, range_proof.rs:770-774; weighted_inner_product.rs:500-504).
+//
+//   k_mb_digits : one lane per (job, generator): scalar -> signed window digits of the table's width
+//   k_mb_msm    : 16 lanes per job: generator terms through table gathers (no doublings), job-specific
+//                 points through GLV + 4-bit windows, lane tree sum -> XYZZ per job
+// followed by the shared batched normalisation (k_xyzz_to_affine) and export.
+#include <hip/hip_runtime.h>
+
+#include "ec.h"
+#include "ecmul.h"
+#include "fq.h"
+#include "kernels.h"
+
+namespace bp {
+
+__global__ void k_mb_digits(const uint8_t* __restrict__ scalars_be, size_t total, int c, int W, int16_t* __restrict__ digits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    fq k = fq_from_be_reduce(scalars_be + 32 * i);
+    int16_t* out = digits + i * (size_t)W;
+    uint32_t carry = 0;
+    const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
+    for (int w = 0; w < W; w++) {
+        int bit = w * c;
+        uint32_t v = 0;
+        if (bit < 256) {
+            int limb = bit >> 5, sh = bit & 31;
+            uint64_t two = k.v[limb];
+            if (limb + 1 < 8) two |= (uint64_t)k.v[limb + 1] << 32;
+            v = (uint32_t)(two >> sh) & mask;
+        }
+        v += carry;
+        int d;
+        if (v > half) {
+            d = (int)v - (int)(1u << c);
+            carry = 1;
+        } else {
+            d = (int)v;
+            carry = 0;
+        }
+        out[w] = (int16_t)d;
+    }
+}
+
+#define MB_TP 16
+__global__ __launch_bounds__(256, 2) void k_mb_msm(size_t njobs, int np, const affine_mem* __restrict__ table, int c, int W,
+                                                   const int16_t* __restrict__ digF, const uint8_t* __restrict__ has_gen,
+                                                   const affine_mem* __restrict__ xpts, const uint8_t* __restrict__ xsc_be,
+                                                   const uint32_t* __restrict__ xoff, xyzz* __restrict__ vartab, int8_t* __restrict__ vardig,
+                                                   xyzz* __restrict__ out) {
+    __shared__ xyzz red[256];
+    const int tid = threadIdx.x, lane = tid % MB_TP;
+    const size_t job = (size_t)blockIdx.x * (256 / MB_TP) + tid / MB_TP;
+    const int NB = 1 << (c - 1);
+    xyzz acc = xyzz_inf();
+    if (job < njobs) {
+        if (has_gen[job]) {
+            const int nfw = np * W;
+            const int16_t* dg = digF + job * (size_t)nfw;
+            for (int idx = lane; idx < nfw; idx += MB_TP) {
+                int d = dg[idx];
+                if (d != 0) {
+                    affine e = affine_load(table[(size_t)idx * NB + ((d < 0 ? -d : d) - 1)]);
+                    if (d < 0) e.y = fp_neg(e.y);
+                    xyzz_madd(acc, e);
+                }
+            }
+        }
+        const size_t gl = (size_t)blockIdx.x * 256 + tid;
+        xyzz* tab = vartab + gl * ECMUL_NT;
+        int8_t* dig = vardig + gl * ECMUL_DIGB;
+        for (uint32_t v = xoff[job] + lane; v < xoff[job + 1]; v += MB_TP) {
+            xyzz t = ec_mul_glv_multi<1>([&](int) { return affine_load(xpts[v]); }, [&](int) { return fq_from_be_reduce(xsc_be + 32 * (size_t)v); }, 1,
+                                         tab, dig);
+            xyzz_add(acc, t);
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int off = MB_TP / 2; off >= 1; off >>= 1) {
+        if (lane < off) {
+            xyzz v = red[tid];
+            xyzz o = red[tid + off];
+            xyzz_add(v, o);
+            red[tid] = v;
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && job < njobs) out[job] = red[tid];
+}
+
+hipError_t launch_mb_digits(const uint8_t* scalars_be, size_t total, int c, int W, int16_t* digits, hipStream_t st) {
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mb_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scalars_be, total, c, W, digits);
+    return hipGetLastError();
+}
+size_t mb_vartab_bytes(size_t njobs) {
+    size_t blocks = (njobs + (256 / MB_TP) - 1) / (256 / MB_TP);
+    return blocks * 256 * (ECMUL_NT * sizeof(xyzz) + ECMUL_DIGB);
+}
+hipError_t launch_mb_msm(size_t njobs, int np, const affine_mem* table, int c, int W, const int16_t* digF, const uint8_t* has_gen,
+                         const affine_mem* xpts, const uint8_t* xsc_be, const uint32_t* xoff, xyzz* vartab, xyzz* out, hipStream_t st) {
+    unsigned blocks = (unsigned)((njobs + (256 / MB_TP) - 1) / (256 / MB_TP));
+    int8_t* vardig = reinterpret_cast<int8_t*>(vartab + (size_t)blocks * 256 * ECMUL_NT);
+    hipLaunchKernelGGL(k_mb_msm, dim3(blocks), dim3(256), 0, st, njobs, np, table, c, W, digF, has_gen, xpts, xsc_be, xoff, vartab, vardig, out);
+    return hipGetLastError();
+}
+
+}  // namespace bp

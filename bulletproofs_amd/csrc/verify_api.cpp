@@ -241,6 +241,77 @@ int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bi
     return BP_OK;
 }
 
+int bp_msm_batch(bp_ctx* ctx, const bp_gens* gens, const bp_msm_job* jobs, size_t njobs, uint8_t* out_xy) {
+    if (!ctx || !gens || (njobs && (!jobs || !out_xy))) return BP_EINVAL;
+    if (njobs == 0) return BP_OK;
+    if (gens->device != ctx->device) return BP_EINVAL;
+    const int np = gens->np;
+    // pack on the host: generator scalars [njobs][np][32] (zero rows for jobs without), extras concatenated
+    std::vector<uint8_t> gsc(njobs * (size_t)np * 32, 0), has(njobs, 0);
+    std::vector<uint32_t> xoff(njobs + 1, 0);
+    size_t nx = 0;
+    for (size_t j = 0; j < njobs; j++) {
+        if (jobs[j].n_extra && (!jobs[j].extra_points_xy || !jobs[j].extra_scalars_be)) return BP_EINVAL;
+        nx += jobs[j].n_extra;
+        if (nx >= ((size_t)1 << 31)) return BP_EINVAL;
+        xoff[j + 1] = (uint32_t)nx;
+        if (jobs[j].gen_scalars_be) {
+            memcpy(&gsc[j * (size_t)np * 32], jobs[j].gen_scalars_be, (size_t)np * 32);
+            has[j] = 1;
+        }
+    }
+    std::vector<uint8_t> xp(nx ? nx * 64 : 64), xs(nx ? nx * 32 : 32);
+    for (size_t j = 0; j < njobs; j++) {
+        if (!jobs[j].n_extra) continue;
+        memcpy(&xp[(size_t)xoff[j] * 64], jobs[j].extra_points_xy, jobs[j].n_extra * 64);
+        memcpy(&xs[(size_t)xoff[j] * 32], jobs[j].extra_scalars_be, jobs[j].n_extra * 32);
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t st = ctx->stream;
+    int rc;
+    DevBuf &b_gsc = ctx->scratch[0], &b_dig = ctx->scratch[2], &b_x = ctx->scratch[3], &b_misc = ctx->scratch[4], &b_out = ctx->scratch[5];
+    const size_t nxa = nx ? nx : 1;
+    if ((rc = b_gsc.reserve(gsc.size())) != BP_OK) return rc;
+    if ((rc = b_dig.reserve(njobs * (size_t)np * gens->W * sizeof(int16_t))) != BP_OK) return rc;
+    if ((rc = b_x.reserve(nxa * (64 + 32 + sizeof(affine_mem)))) != BP_OK) return rc;
+    if ((rc = b_misc.reserve((njobs + 1) * 4 + njobs + 16)) != BP_OK) return rc;
+    if ((rc = b_out.reserve(njobs * (sizeof(xyzz) + sizeof(affine_mem) + 64))) != BP_OK) return rc;
+    if ((rc = ctx->vartab.reserve(mb_vartab_bytes(njobs))) != BP_OK) return rc;
+    uint8_t* d_xbe = (uint8_t*)b_x.p;
+    uint8_t* d_xsc = d_xbe + nxa * 64;
+    affine_mem* d_xpts = (affine_mem*)(d_xsc + nxa * 32);
+    uint32_t* d_xoff = (uint32_t*)b_misc.p;
+    uint8_t* d_has = (uint8_t*)(d_xoff + njobs + 1);
+    xyzz* d_res = (xyzz*)b_out.p;
+    affine_mem* d_aff = (affine_mem*)(d_res + njobs);
+    uint8_t* d_be = (uint8_t*)(d_aff + njobs);
+    HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), st), "memset err");
+    HIPCHK(hipMemcpyAsync(b_gsc.p, gsc.data(), gsc.size(), hipMemcpyHostToDevice, st), "memcpy gen scalars");
+    HIPCHK(hipMemcpyAsync(d_xbe, xp.data(), nxa * 64, hipMemcpyHostToDevice, st), "memcpy extra points");
+    HIPCHK(hipMemcpyAsync(d_xsc, xs.data(), nxa * 32, hipMemcpyHostToDevice, st), "memcpy extra scalars");
+    HIPCHK(hipMemcpyAsync(d_xoff, xoff.data(), (njobs + 1) * 4, hipMemcpyHostToDevice, st), "memcpy offsets");
+    HIPCHK(hipMemcpyAsync(d_has, has.data(), njobs, hipMemcpyHostToDevice, st), "memcpy flags");
+    HIPCHK(launch_ingest_points(d_xbe, d_xpts, nx, ctx->d_err, st), "ingest");
+    HIPCHK(launch_mb_digits((const uint8_t*)b_gsc.p, njobs * (size_t)np, gens->c, gens->W, (int16_t*)b_dig.p, st), "mb_digits");
+    HIPCHK(launch_mb_msm(njobs, np, gens->d_table, gens->c, gens->W, (const int16_t*)b_dig.p, d_has, d_xpts, d_xsc, d_xoff, (xyzz*)ctx->vartab.p,
+                         d_res, st),
+           "mb_msm");
+    HIPCHK(launch_xyzz_to_affine(d_res, d_aff, njobs, st), "normalize");
+    HIPCHK(launch_export_points(d_aff, d_be, njobs, st), "export");
+    std::vector<uint8_t> tmp(njobs * 64);
+    int h_err = 0;
+    HIPCHK(hipMemcpyAsync(tmp.data(), d_be, njobs * 64, hipMemcpyDeviceToHost, st), "memcpy out");
+    HIPCHK(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, st), "memcpy err");
+    HIPCHK(hipStreamSynchronize(st), "sync");
+    if (h_err) {
+        set_error_msg("input point not on curve");
+        return BP_EPOINT;
+    }
+    memcpy(out_xy, tmp.data(), njobs * 64);
+    return BP_OK;
+}
+
 int bp_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
                                const uint8_t* coms_xy, size_t nproofs, uint8_t* verdicts) {
     if (!ctx || !gens || m <= 0) return BP_EINVAL;

@@ -81,6 +81,22 @@ int bp_gens_create(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t
 void bp_gens_destroy(bp_gens* gens);
 size_t bp_gens_table_bytes(const bp_gens* gens);
 
+/* bp_msm_batch — many small MSMs that share the generator prefix: for every job j
+ *     out_j = sum_p gen_scalars[p] * gens[p]  +  sum_e extra_scalars[e] * extra_points[e]
+ * with gens in the order g_vec[nm], h_vec[nm], G, H.  Replaces the single-MSM idiom of the fast
+ * verifiers when many statements are checked at once (inner_product.rs:334-338, range_proof.rs:770-774,
+ * weighted_inner_product.rs:500-504, range_proof_wip.rs:598-602): the generator terms come from the
+ * resident fixed-base table (no doublings), the job-specific points are multiplied individually.
+ * gen_scalars_be may be NULL (no generator terms); scalars are any 256-bit value (reduced mod q);
+ * out_xy receives njobs * 64 bytes.  BP_EPOINT if an extra point is not on the curve. */
+typedef struct bp_msm_job {
+    const uint8_t* gen_scalars_be;  /* (2nm+2) * 32 bytes or NULL */
+    const uint8_t* extra_points_xy; /* n_extra * 64 bytes */
+    const uint8_t* extra_scalars_be; /* n_extra * 32 bytes */
+    size_t n_extra;
+} bp_msm_job;
+int bp_msm_batch(bp_ctx* ctx, const bp_gens* gens, const bp_msm_job* jobs, size_t njobs, uint8_t* out_xy);
+
 /* bp_rangeproof_verify_batch — `RangeProof::aggregated_verify` (range_proof.rs:537-782) for
  * nproofs independent proofs that share the generators: every challenge, the scalar vector and the
  * single 2nm+2k+m+5-term MSM are computed on the GPU; verdicts[i] is one of the BP_VERDICT_* codes.

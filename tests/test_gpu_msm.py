@@ -148,3 +148,41 @@ def test_msm_full_size_2pow20(ctx, oracle_c):
     for i in range(n):
         acc += int.from_bytes(rbb[32 * i:32 * i + 32], "big") * int.from_bytes(kbb[32 * i:32 * i + 32], "big")
     assert got == ec.enc64(oracle_c.mul(ec.G, acc % ec.Q))
+
+
+def test_msm_batch_shared_generators(ctx, oracle_c):
+    """bp_msm_batch: jobs sharing the generator prefix (fixed-base table) plus job-specific points.
+    Checked term by term against the oracle fold idiom; includes a job without generator scalars, a job
+    without extras, zero / unreduced scalars, an infinity extra point and an empty job."""
+    import bulletproofs_amd as bpa
+    from oracle import curv
+    rng = random.Random(4242)
+    g_vec, h_vec, G, H = curv.bp_generators(8, 1)
+    gens_pts = g_vec + h_vec + [G, H]
+    gens = bpa.Gens(ctx, b"".join(ec.enc64(p) for p in g_vec), b"".join(ec.enc64(p) for p in h_vec), ec.enc64(G), ec.enc64(H), 6)
+    extra_pool = _rand_points(rng, 12, oracle_c)
+    jobs, want = [], []
+    for j in range(21):
+        gs = [rng.randrange(ec.Q) for _ in gens_pts]
+        if j == 3:
+            gs[0], gs[5] = 0, 2**256 - 1
+        ne = [0, 1, 5, 12][j % 4]
+        xp = [extra_pool[rng.randrange(12)] for _ in range(ne)]
+        xs = [rng.randrange(2**256) for _ in range(ne)]
+        if j == 6 and ne:
+            xp[0] = None
+        use_g = j != 5
+        if j == 8:
+            use_g, xp, xs = False, [], []
+        acc = oracle_c.msm_naive(gens_pts, [s % ec.Q for s in gs], None) if use_g else None
+        if xp:
+            acc = oracle_c.msm_naive(xp, [s % ec.Q for s in xs], acc)
+        want.append(ec.enc64(acc))
+        pb, sb = _pack(xp, xs)
+        jobs.append((b"".join((s % 2**256).to_bytes(32, "big") for s in gs) if use_g else None, pb, sb))
+    try:
+        got = ctx.msm_batch(gens, jobs)
+        assert [got[64 * i:64 * i + 64] for i in range(len(jobs))] == want
+        assert ctx.msm_batch(gens, []) == b""
+    finally:
+        gens.close()
