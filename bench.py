@@ -48,8 +48,9 @@ def parse():
     ap.add_argument("--proofs-per-gpu", type=int, default=16384)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per proof in k_bpv_msm (16/32/64)")
     ap.add_argument("--window-bits", type=int, default=0, help="fixed-base table window (0 = auto)")
-    ap.add_argument("--workload", default="verify", choices=["verify", "msm"],
-                    help="verify = headline metric (default); msm = raw 2^20-point Pippenger MSM, points sharded over the ranks")
+    ap.add_argument("--workload", default="verify", choices=["verify", "msm", "prove"],
+                    help="verify = headline metric (default); msm = raw 2^20-point Pippenger MSM, points sharded over the ranks; "
+                         "prove = single-proof prove / verify latencies of BASELINE.json configs[0], [1], [3] (one GPU)")
     ap.add_argument("--msm-log2", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-check", action="store_true", help="timing experiments only: do not compare verdicts")
@@ -177,10 +178,63 @@ def bench_msm(args):
         dist.destroy_process_group()
 
 
+def bench_prove(args):
+    """Single-proof latencies through the C ABI (protocol layer in C++ over the GPU primitives):
+    BASELINE.json configs[0] (BP n=64 m=1), configs[1] (BP n=64 m=16), configs[3] (BP+ n=64 m=64).
+    Inputs are the golden fixtures (tests/golden); every produced proof is compared with the fixture bytes."""
+    import bulletproofs_amd as bpa
+    ctx = bpa.Context(int(os.environ.get("LOCAL_RANK", "0")))
+
+    def be(xs):
+        return b"".join(int(x, 16).to_bytes(32, "big") for x in xs)
+
+    def load(name, idx=None):
+        with open(os.path.join(ROOT, "tests", "golden", name)) as f:
+            d = json.load(f)
+        return d if idx is None else d[idx]
+
+    cases = [("C1 BP n=64 m=1", 0, load("bp_cases.json", 3)), ("C2 BP n=64 m=16", 0, load("bp_c2_n64_m16.json")),
+             ("C4 BP+ n=64 m=64", 1, load("bpplus_c4_n64_m64.json"))]
+    rows = []
+    for name, kind, case in cases:
+        n, m = case["n"], case["m"]
+        g, h, G, H = bpa.generate_bases(kind, bpa.KZEN_SEED, n, m)
+        gens = bpa.Gens(ctx, g, h, G, H, 0)
+        sec, bl, tape = be(case["secrets"]), be(case["blindings"]), bytes.fromhex(case["tape"])
+        coms = b"".join(bytes.fromhex(c) for c in case["commitments"])
+        prove = ctx.wip_rangeproof_prove if kind else ctx.rangeproof_prove
+        verify = ctx.wip_rangeproof_verify if kind else ctx.rangeproof_verify
+
+        def timeit(fn, reps):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r = fn()
+            return (time.perf_counter() - t0) / reps * 1e3, r
+
+        reps = max(1, args.steps // 4)
+        t_prove, proof = timeit(lambda: prove(gens, n, sec, bl, tape), reps)
+        assert proof.hex() == case["proof"], "proof bytes differ from the golden fixture"
+        row = {"config": name, "prove_ms": t_prove, "proof_bytes": len(proof)}
+        for mode, label in ((2, "aggregated_verify_ms"), (1, "fast_verify_ms"), (0, "verify_ms")):
+            if kind and mode == 1:
+                continue
+            t, v = timeit(lambda: verify(gens, n, m, proof, coms, mode), reps)
+            assert v == 0
+            row[label] = t
+        rows.append(row)
+        gens.close()
+    print(json.dumps({"metric": "single-proof latency (ms), secp256k1 range proofs through the C ABI", "unit": "ms", "n_gpus": 1,
+                      "higher_is_better": False, "data": "golden fixtures (tests/golden), proof bytes checked", "rows": rows}), flush=True)
+    ctx.close()
+
+
 def main():
     args = parse()
     if args.workload == "msm":
         return bench_msm(args)
+    if args.workload == "prove":
+        return bench_prove(args)
     import torch
     import torch.distributed as dist
     import bulletproofs_amd as bpa

@@ -186,8 +186,7 @@ int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scal
         if ((rc = ctx->digits.reserve((size_t)W * pl.npad * sizeof(int16_t))) != BP_OK) return rc;
         if ((rc = ctx->srt[0].reserve((size_t)W * pl.nchunks * NB * 4)) != BP_OK) return rc;
         if ((rc = ctx->srt[1].reserve((size_t)W * (NB + 1) * 4 + ((size_t)W * NB + 1) * 4)) != BP_OK) return rc;
-        if ((rc = ctx->srt[2].reserve((size_t)W * pl.npad * 4)) != BP_OK) return rc;
-        if ((rc = ctx->srt[3].reserve((size_t)W * pl.npad * 2)) != BP_OK) return rc;
+        if ((rc = ctx->srt[2].reserve((size_t)W * pl.npad * 8)) != BP_OK) return rc;
         if ((rc = ctx->srt[4].reserve((size_t)W * NB * sizeof(xyzz))) != BP_OK) return rc;
         if ((rc = ctx->srt[5].reserve((size_t)W * pl.nseg * sizeof(xyzz))) != BP_OK) return rc;
         if ((rc = ctx->srt[6].reserve((size_t)W * nout * sizeof(xyzz))) != BP_OK) return rc;
@@ -195,8 +194,7 @@ int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scal
         b.cnt = (uint32_t*)ctx->srt[0].p;
         b.bstart = (uint32_t*)ctx->srt[1].p;
         b.queue = b.bstart + (size_t)W * (NB + 1);
-        b.ent = (uint32_t*)ctx->srt[2].p;
-        b.bkt = (uint16_t*)ctx->srt[3].p;
+        b.ent = (uint2*)ctx->srt[2].p;
         b.Bk = (xyzz*)ctx->srt[4].p;
         b.Pseg = (xyzz*)ctx->srt[5].p;
         b.RC = (xyzz*)ctx->srt[6].p;

@@ -28,8 +28,8 @@ struct SortedPlan {
     size_t npad;
 };
 struct SortedBufs {
-    uint32_t *cnt, *bstart, *ent, *queue;
-    uint16_t* bkt;
+    uint32_t *cnt, *bstart, *queue;
+    uint2* ent;
     xyzz *Bk, *Pseg, *RC;
 };
 hipError_t launch_msm_sorted(const affine_mem* pts, const affine_mem* lam, size_t n1, const int16_t* digits, size_t n2, const SortedPlan& pl,

@@ -9,13 +9,13 @@
 //   k_srt_colscan  exclusive scan over the chunks of every bucket count, bucket sizes out
 //   k_srt_bstart   per window: exclusive scan of the bucket sizes -> bucket start offsets
 //   k_srt_scatter  (chunk, window): LDS cursors; writes the window's points sorted by bucket
-//                  (entry = virtual point index | sign bit, plus the bucket id as u16)
+//                  (8-byte entry = virtual point index | sign bit, bucket id)
 //   k_srt_acc      one lane per SEGMENT of L consecutive sorted entries (not per bucket): every lane
 //                  performs exactly L mixed additions whatever the bucket sizes are.  A run that starts
 //                  inside the segment is the beginning of its bucket and is written to Bk[bucket]; the
 //                  run at the segment start goes to Pseg[segment].
 //   k_srt_finalize one lane per bucket: Bk[b] (+)= the Pseg of every segment boundary inside the bucket;
-//                  buckets spanning many segments are queued and summed by one wave each (k_srt_finalize_big)
+//                  buckets spanning many segments are queued and summed by one workgroup each (k_srt_finalize_big)
 //   k_srt_rowcol   bucket index b = hi*LO + lo: row sums R_hi and column sums C_lo, one wave each
 //   k_srt_window   sum_b (b+1) B_b = sum_lo lo*C_lo + sum_hi (LO*hi + 1) R_hi by an in-LDS suffix scan
 //
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(SRT_T) void k_srt_bstart(uint32_t* __restrict__ bst
 
 __global__ __launch_bounds__(SRT_T) void k_srt_scatter(const int16_t* __restrict__ digits, size_t n2, size_t npad, int CH, int NB,
                                                        const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bstart,
-                                                       uint32_t* __restrict__ ent, uint16_t* __restrict__ bkt) {
+                                                       uint2* __restrict__ ent) {
     extern __shared__ uint32_t srt_h[];
     const int tid = threadIdx.x, chunk = blockIdx.x, w = blockIdx.y, nchunks = gridDim.x;
     const uint32_t* o = cnt + ((size_t)w * nchunks + chunk) * NB;
@@ -103,22 +103,19 @@ __global__ __launch_bounds__(SRT_T) void k_srt_scatter(const int16_t* __restrict
     const size_t base = (size_t)chunk * CH;
     const int len = base >= n2 ? 0 : (int)((n2 - base) < (size_t)CH ? (n2 - base) : (size_t)CH);
     const int16_t* dg = digits + (size_t)w * npad + base;
-    uint32_t* E = ent + (size_t)w * npad;
-    uint16_t* K = bkt + (size_t)w * npad;
+    uint2* E = ent + (size_t)w * npad;
     for (int i = tid; i < len; i += SRT_T) {
         int d = dg[i];
         if (d != 0) {
             int b = (d < 0 ? -d : d) - 1;
             uint32_t pos = atomicAdd(&srt_h[b], 1u);
-            E[pos] = (uint32_t)(base + i) | (d < 0 ? 0x80000000u : 0u);
-            K[pos] = (uint16_t)b;
+            E[pos] = make_uint2((uint32_t)(base + i) | (d < 0 ? 0x80000000u : 0u), (uint32_t)b);  // one 8-byte store per entry
         }
     }
 }
 
 __global__ __launch_bounds__(256, 2) void k_srt_acc(const affine_mem* __restrict__ pts, const affine_mem* __restrict__ lam, size_t n1,
-                                                    const uint32_t* __restrict__ ent, const uint16_t* __restrict__ bkt,
-                                                    const uint32_t* __restrict__ bstart, size_t npad, int NB, int L, int nseg, int W,
+                                                    const uint2* __restrict__ ent, const uint32_t* __restrict__ bstart, size_t npad, int NB, int L, int nseg, int W,
                                                     xyzz* __restrict__ Bk, xyzz* __restrict__ Pseg) {
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int w = (int)(g / nseg), t = (int)(g % nseg);
@@ -127,13 +124,13 @@ __global__ __launch_bounds__(256, 2) void k_srt_acc(const affine_mem* __restrict
     const uint32_t j0 = (uint32_t)t * L;
     if (j0 >= Nw) return;
     const uint32_t j1 = (j0 + L < Nw) ? j0 + L : Nw;
-    const uint32_t* E = ent + (size_t)w * npad;
-    const uint16_t* K = bkt + (size_t)w * npad;
+    const uint2* E = ent + (size_t)w * npad;
     xyzz acc = xyzz_inf();
-    int cur = K[j0];
+    int cur = (int)E[j0].y;
     bool atstart = true;
     for (uint32_t j = j0; j < j1; j++) {
-        int b = K[j];
+        const uint2 ev = E[j];
+        int b = (int)ev.y;
         if (b != cur) {
             if (atstart)
                 Pseg[(size_t)w * nseg + t] = acc;
@@ -143,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void k_srt_acc(const affine_mem* __restrict
             cur = b;
             atstart = false;
         }
-        uint32_t e = E[j];
+        uint32_t e = ev.x;
         size_t v = e & 0x7fffffffu;
         affine p = affine_load(v < n1 ? pts[v] : lam[v - n1]);
         if (e >> 31) p.y = fp_neg(p.y);
@@ -183,10 +180,11 @@ __global__ __launch_bounds__(256, 2) void k_srt_finalize(const uint32_t* __restr
     Bk[(size_t)w * NB + b] = r;
 }
 
-// one wave per queued bucket: lanes stride over the bucket's segment partials, LDS tree, lane 0 stores
-__global__ __launch_bounds__(64) void k_srt_finalize_big(const uint32_t* __restrict__ bstart, int NB, int L, int nseg, xyzz* __restrict__ Bk,
-                                                         const xyzz* __restrict__ Pseg, const uint32_t* __restrict__ queue) {
-    __shared__ xyzz red[64];
+// one 256-lane workgroup per queued bucket: lanes stride over the bucket's segment partials, LDS tree,
+// lane 0 stores (a bucket holding every entry of a window, 2^21 / L partials, costs 256 + 8 addition steps)
+__global__ __launch_bounds__(256) void k_srt_finalize_big(const uint32_t* __restrict__ bstart, int NB, int L, int nseg, xyzz* __restrict__ Bk,
+                                                          const xyzz* __restrict__ Pseg, const uint32_t* __restrict__ queue) {
+    __shared__ xyzz red[256];
     const int lane = threadIdx.x;
     const uint32_t nq = queue[0];
     for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
@@ -196,13 +194,13 @@ __global__ __launch_bounds__(64) void k_srt_finalize_big(const uint32_t* __restr
         const uint32_t t0 = (s + L - 1) / L, t1 = (e + L - 1) / L;
         xyzz r = xyzz_inf();
         if (lane == 0 && (s % L)) r = Bk[(size_t)w * NB + b];
-        for (uint32_t t = t0 + lane; t < t1; t += 64) {
+        for (uint32_t t = t0 + lane; t < t1; t += 256) {
             xyzz o = Pseg[(size_t)w * nseg + t];
             xyzz_add(r, o);
         }
         red[lane] = r;
         __syncthreads();
-        for (int off = 32; off >= 1; off >>= 1) {
+        for (int off = 128; off >= 1; off >>= 1) {
             if (lane < off) {
                 xyzz v = red[lane];
                 xyzz u = red[lane + off];
@@ -298,15 +296,15 @@ hipError_t launch_msm_sorted(const affine_mem* pts, const affine_mem* lam, size_
     hipLaunchKernelGGL(k_srt_hist, gcw, dim3(SRT_T), lds, st, digits, n2, pl.npad, pl.CH, NB, b.cnt);
     hipLaunchKernelGGL(k_srt_colscan, dim3((unsigned)((NB + 255) / 256), (unsigned)W), dim3(256), 0, st, b.cnt, pl.nchunks, NB, b.bstart);
     hipLaunchKernelGGL(k_srt_bstart, dim3((unsigned)W), dim3(SRT_T), 0, st, b.bstart, NB);
-    hipLaunchKernelGGL(k_srt_scatter, gcw, dim3(SRT_T), lds, st, digits, n2, pl.npad, pl.CH, NB, b.cnt, b.bstart, b.ent, b.bkt);
+    hipLaunchKernelGGL(k_srt_scatter, gcw, dim3(SRT_T), lds, st, digits, n2, pl.npad, pl.CH, NB, b.cnt, b.bstart, b.ent);
     size_t nthr = (size_t)W * pl.nseg;
-    hipLaunchKernelGGL(k_srt_acc, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, pts, lam, n1, b.ent, b.bkt, b.bstart, pl.npad, NB, pl.L,
+    hipLaunchKernelGGL(k_srt_acc, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, pts, lam, n1, b.ent, b.bstart, pl.npad, NB, pl.L,
                        pl.nseg, W, b.Bk, b.Pseg);
     nthr = (size_t)W * NB;
     hipError_t e = hipMemsetAsync(b.queue, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_srt_finalize, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, b.bstart, NB, pl.L, pl.nseg, W, b.Bk, b.Pseg, b.queue);
-    hipLaunchKernelGGL(k_srt_finalize_big, dim3(2048), dim3(64), 0, st, b.bstart, NB, pl.L, pl.nseg, b.Bk, b.Pseg, b.queue);
+    hipLaunchKernelGGL(k_srt_finalize_big, dim3(2048), dim3(256), 0, st, b.bstart, NB, pl.L, pl.nseg, b.Bk, b.Pseg, b.queue);
     const int nout = (1 << pl.lo_bits) + (NB >> pl.lo_bits);
     hipLaunchKernelGGL(k_srt_rowcol, dim3((unsigned)((nout + 3) / 4), (unsigned)W), dim3(256), 0, st, b.Bk, NB, pl.lo_bits, b.RC);
     hipLaunchKernelGGL(k_srt_window, dim3((unsigned)W), dim3(256), 0, st, b.RC, NB, pl.lo_bits, wsum);
