@@ -117,7 +117,10 @@ SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
     pl.nchunks = (int)((n2 + ch - 1) / ch);
     if (pl.nchunks < 1) pl.nchunks = 1;
     pl.npad = (size_t)pl.nchunks * ch;
+    // segment length: ~4 segments per average bucket, at least 32 (lanes of a wave then do equal work
+    // and k_srt_finalize adds only a few partial sums per bucket)
     pl.L = 32;
+    while (pl.L < 256 && (size_t)pl.L * 8 <= n2 / (size_t)pl.NB) pl.L *= 2;
     if (const char* e = getenv("BP_MSM_L")) pl.L = atoi(e) > 0 ? atoi(e) : 32;
     pl.nseg = (int)((pl.npad + pl.L - 1) / pl.L);
     pl.lo_bits = c / 2;  // LO = 2^lo_bits, HI = NB / LO; LO + HI <= 256 for c <= 15
@@ -158,7 +161,7 @@ int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scal
     const size_t n2 = 2 * n;
     int path = ctx->msm_path;  // 0 auto, 1 LDS slices, 2 sorted
     if (const char* e = getenv("BP_MSM_PATH")) path = atoi(e);
-    if (path == 0) path = n2 >= ((size_t)1 << 15) ? 2 : 1;
+    if (path == 0) path = n2 >= 256 ? 2 : 1;  // measured: the sorted path wins from 2^7 points up
     if ((rc = ctx->lam.reserve(n * sizeof(affine_mem))) != BP_OK) return rc;
     HIPCHK(launch_glv_expand(d_points, (affine_mem*)ctx->lam.p, n, st), "glv expand");
     const affine_mem* lam = (const affine_mem*)ctx->lam.p;
