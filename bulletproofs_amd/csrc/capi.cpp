@@ -88,9 +88,11 @@ MsmPlan plan_msm(size_t n2, int forced_c) {
     return pl;
 }
 
-// Plan of the sorted (large-N) path (msm_sorted.hip).  Cost model: W * (n2 + 3 NB) mixed-add
-// equivalents (bucket accumulation + finalize/row/column additions); c <= 15 (int16 digits, 64 KB
-// LDS histograms).
+// Plan of the sorted path (msm_sorted.hip).  Cost model in mixed-add equivalents of whole-GPU
+// throughput: W * (n2 + 3 NB) for bucket accumulation + finalize/row/column additions, plus
+// W * 146000 for the serial Horner step (one window = a full addition and two coordinate conversions
+// in a lone wave, ~7.7 us, the time in which the GPU retires ~146k mixed additions): small MSMs are
+// latency-bound and want few windows.  c <= 15 (int16 digits, 64 KB LDS histograms).
 SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
     SortedPlan pl;
     if (const char* e = getenv("BP_MSM_C")) forced_c = atoi(e);
@@ -100,7 +102,7 @@ SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
     } else {
         double best = 0;
         for (int cc = 6; cc <= 15; cc++) {
-            double cost = (double)glv_windows(cc) * ((double)n2 + 3.0 * (double)(1 << (cc - 1)));
+            double cost = (double)glv_windows(cc) * ((double)n2 + 3.0 * (double)(1 << (cc - 1)) + 146000.0);
             if (c == 0 || cost < best) {
                 best = cost;
                 c = cc;
@@ -119,8 +121,11 @@ SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
     pl.npad = (size_t)pl.nchunks * ch;
     // segment length: ~4 segments per average bucket, at least 32 (lanes of a wave then do equal work
     // and k_srt_finalize adds only a few partial sums per bucket)
+    // Small MSMs are latency-bound: shorter segments (more lanes, shorter serial chains) while the grid
+    // still has fewer than ~64k lanes.
     pl.L = 32;
     while (pl.L < 256 && (size_t)pl.L * 8 <= n2 / (size_t)pl.NB) pl.L *= 2;
+    while (pl.L > 4 && (size_t)pl.W * n2 / pl.L < 65536) pl.L /= 2;
     if (const char* e = getenv("BP_MSM_L")) pl.L = atoi(e) > 0 ? atoi(e) : 32;
     pl.nseg = (int)((pl.npad + pl.L - 1) / pl.L);
     pl.lo_bits = c / 2;  // LO = 2^lo_bits, HI = NB / LO; LO + HI <= 256 for c <= 15
