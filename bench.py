@@ -99,7 +99,7 @@ def cpu_baseline(batch, sample):
 
 def bench_msm(args):
     """BASELINE.json configs[4]: raw Pippenger MSM of 2^k secp256k1 points; points sharded N/G per rank,
-    per-rank partial sums all-gathered over RCCL and added (bulletproofs_amd/batch.py: msm_sharded).
+    per-rank per-window partial sums all-gathered over RCCL, added, one Horner combine (bulletproofs_amd/batch.py: msm_sharded).
     Strong scaling (total work fixed).  Inputs resident in HBM; the 64-byte result returns to the host."""
     import hashlib
     import torch
@@ -134,15 +134,13 @@ def bench_msm(args):
     d_sc = torch.frombuffer(bytearray(scal), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()
 
+    cwin = bpa.msm_auto_window(bt.largest_shard(N, world))
+
     def step():
-        part = ctx.msm_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
         if world == 1:
-            return part
-        buf = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev)
-        parts = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(parts, buf)
-        allp = b"".join(bytes(p.cpu().numpy().tobytes()) for p in parts)
-        return ctx.msm(allp, (1).to_bytes(32, "big") * world)
+            return ctx.msm_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
+        return bt.msm_sharded(N, lambda lo_, hi_: ctx.msm_partial_device(d_pts.data_ptr(), d_sc.data_ptr(), hi_ - lo_, cwin),
+                              lambda parts, g: ctx.msm_combine(parts, g, cwin), dev)
 
     for _ in range(args.warmup):
         res = step()

@@ -9,6 +9,7 @@ from ._lib import (  # noqa: F401
     Context,
     Gens,
     generate_bases,
+    msm_auto_window,
     KZEN_SEED,
     lib,
     lib_path,

@@ -19,6 +19,11 @@ EXPORTED_SYMBOLS = [
     "bp_msm_set_window",
     "bp_msm_set_path",
     "bp_msm_batch",
+    "bp_msm_auto_window",
+    "bp_msm_partial_bytes",
+    "bp_msm_partial_device",
+    "bp_msm_partial",
+    "bp_msm_combine",
     "bp_gens_create",
     "bp_gens_destroy",
     "bp_gens_table_bytes",
@@ -99,6 +104,16 @@ def lib():
     L.bp_fold_bases.restype = i32
     L.bp_fixed_base_mul_batch.argtypes = [vp, cp, sz, cp]
     L.bp_fixed_base_mul_batch.restype = i32
+    L.bp_msm_auto_window.argtypes = [sz]
+    L.bp_msm_auto_window.restype = i32
+    L.bp_msm_partial_bytes.argtypes = [i32]
+    L.bp_msm_partial_bytes.restype = sz
+    L.bp_msm_partial_device.argtypes = [vp, vp, vp, sz, i32, cp]
+    L.bp_msm_partial_device.restype = i32
+    L.bp_msm_partial.argtypes = [vp, cp, cp, sz, i32, cp]
+    L.bp_msm_partial.restype = i32
+    L.bp_msm_combine.argtypes = [vp, cp, sz, i32, cp, cp]
+    L.bp_msm_combine.restype = i32
     L.bp_msm_batch.argtypes = [vp, vp, vp, sz, cp]
     L.bp_msm_batch.restype = i32
     L.bp_generate_bases.argtypes = [i32, ctypes.c_uint64, sz, sz, cp, cp, cp, cp]
@@ -225,6 +240,23 @@ class Context:
         _check(lib().bp_fold_bases(self._h, bytes(lo_xy), bytes(hi_xy), n, bytes(s_lo), bytes(s_hi), out))
         return out.raw[:64 * n]
 
+    def msm_partial_device(self, d_points, d_scalars, n, c):
+        """Rank-local window sums of a sharded MSM (device pointers in, opaque host bytes out)."""
+        out = ctypes.create_string_buffer(lib().bp_msm_partial_bytes(c))
+        _check(lib().bp_msm_partial_device(self._h, d_points, d_scalars, n, c, out))
+        return out.raw
+
+    def msm_partial(self, points_xy, scalars_be, c):
+        n = len(scalars_be) // 32
+        out = ctypes.create_string_buffer(lib().bp_msm_partial_bytes(c))
+        _check(lib().bp_msm_partial(self._h, bytes(points_xy), bytes(scalars_be), n, c, out))
+        return out.raw
+
+    def msm_combine(self, partials, nparts, c, init_xy=None):
+        out = ctypes.create_string_buffer(64)
+        _check(lib().bp_msm_combine(self._h, bytes(partials), nparts, c, init_xy, out))
+        return out.raw
+
     def msm_batch(self, gens, jobs):
         """jobs: list of (gen_scalars_be or None, extra_points_xy, extra_scalars_be); returns 64 bytes per job."""
         n = len(jobs)
@@ -280,6 +312,11 @@ class Context:
         """Asynchronous device-pointer variant (ints); call sync() before reading verdicts."""
         _check(lib().bp_rangeproof_verify_batch_device(self._h, gens._h, n_bits, m, ctypes.c_void_p(d_proofs), proof_len,
                                                        ctypes.c_void_p(d_coms), nproofs, ctypes.c_void_p(d_verdicts)))
+
+
+def msm_auto_window(n):
+    """Window width the planner picks for an n-term MSM (same on every rank for the same n)."""
+    return lib().bp_msm_auto_window(n)
 
 
 def generate_bases(kind, seed, n_bits, m):

@@ -53,27 +53,33 @@ def verify_batch_sharded(verify_fn, proofs, proof_len, coms, com_len, nproofs, d
     return gather_verdicts(local, nproofs, device)
 
 
-def msm_sharded(msm_fn, points_xy, scalars_be, device=None):
+def msm_sharded(n, partial_fn, combine_fn, device=None):
     """One large MSM across the ranks (SURVEY.md §8e mode (ii)): points are sharded N/G per rank,
-    every rank runs the whole Pippenger pipeline on its shard (all windows, own Horner combine),
-    the per-rank partial sums (one 64-byte canonical point each — group addition is associative, so
-    this equals combining per-window partials) are all-gathered, and every rank adds the G partials
-    with a G-term unit-scalar MSM.  `msm_fn(points_xy, scalars_be) -> 64 bytes` is
-    `lambda p, s: ctx.msm(p, s)` on the GPU box.  Returns the same 64 bytes on every rank."""
+    every rank runs the bucket phase of the Pippenger pipeline on its shard (all windows) and produces
+    its per-window partial sums; the partials (W x 144 bytes per rank) are all-gathered - EC addition
+    is not a reduction operator, so gather + local combine, no all-reduce - and every rank adds the G
+    partials per window and runs ONE Horner combine.
+      partial_fn(lo, hi)      -> bytes     rank-local partial over terms [lo, hi)
+                                           (GPU: ctx.msm_partial_device(d_points, d_scalars, hi - lo, c))
+      combine_fn(parts, G)    -> 64 bytes  (GPU: ctx.msm_combine(parts, G, c))
+    Every rank must return partials of the same length (same window width c: take
+    c = bp_msm_auto_window(largest shard)).  Returns the same 64 bytes on every rank."""
     import torch
     import torch.distributed as dist
-    n = len(scalars_be) // 32
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     lo, hi = shard_range(n, rank, world)
-    part = msm_fn(points_xy[64 * lo:64 * hi], scalars_be[32 * lo:32 * hi])
+    part = partial_fn(lo, hi)
     if world == 1:
-        return part
+        return combine_fn(part, 1)
     buf = torch.frombuffer(bytearray(part), dtype=torch.uint8)
     if device is not None:
         buf = buf.to(device)
     parts = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(parts, buf)
     allp = b"".join(bytes(p.cpu().numpy().tobytes()) for p in parts)
-    ones = (1).to_bytes(32, "big") * world
-    return msm_fn(allp, ones)
+    return combine_fn(allp, world)
+
+
+def largest_shard(n, world):
+    return (n + world - 1) // world

@@ -142,39 +142,32 @@ SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
         }                                \
     } while (0)
 
-// out = init + sum scalars[i] * points[i]; d_points (limb form) and d_scalars_be on device.
-// Leaves the result in ctx->d_result (limb form) and ctx->d_result_be; does not synchronise.
-// Path: GLV split (2n virtual points, 129-bit scalars) -> LDS slice path (small / medium n) or
-// global sorted path (large n) -> Horner over the windows.
-int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scalars_be, size_t n, const affine_mem* d_init) {
+// Window phase of an MSM: wsum[w] = sum of the w-th signed GLV digits times the points, for n >= 1
+// terms; leaves W XYZZ window sums in ctx->wsum and reports the window width / count used.
+// want_c = 0: planner's choice (and its choice of path); otherwise the sorted path with that width.
+// Path: GLV split (2n virtual points, 129-bit scalars) -> LDS slice path (tiny n) or global sorted path.
+static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scalars_be, size_t n, int want_c, int* c_out,
+                                 int* W_out) {
     hipStream_t st = ctx->stream;
     int rc;
-    if ((rc = ctx->wsum.reserve(64 * sizeof(xyzz))) != BP_OK) return rc;
-    if ((rc = ctx->result.reserve(sizeof(affine_mem) + 64)) != BP_OK) return rc;
-    affine_mem* d_res = (affine_mem*)ctx->result.p;
-    uint8_t* d_res_be = (uint8_t*)ctx->result.p + sizeof(affine_mem);
-    if (n == 0) {
-        // empty sum: result = init (or infinity)
-        HIPCHK(hipMemsetAsync(ctx->wsum.p, 0, sizeof(xyzz), st), "memset");
-        HIPCHK(launch_msm_horner((const xyzz*)ctx->wsum.p, 1, 1, d_init, d_res, d_res_be, st), "horner");
-        return BP_OK;
-    }
-    if (n >= ((size_t)1 << 30)) {
-        set_error_msg("msm: more than 2^30 terms");
+    if ((rc = ctx->wsum.reserve(72 * sizeof(xyzz))) != BP_OK) return rc;
+    if (n == 0 || n >= ((size_t)1 << 30)) {
+        set_error_msg("msm: term count out of range");
         return BP_EINVAL;
     }
     const size_t n2 = 2 * n;
     int path = ctx->msm_path;  // 0 auto, 1 LDS slices, 2 sorted
     if (const char* e = getenv("BP_MSM_PATH")) path = atoi(e);
     if (path == 0) path = n2 >= 256 ? 2 : 1;  // measured: the sorted path wins from 2^7 points up
+    if (want_c) path = 2;
+    const int forced_c = want_c ? want_c : ctx->forced_c;
     if ((rc = ctx->lam.reserve(n * sizeof(affine_mem))) != BP_OK) return rc;
     HIPCHK(launch_glv_expand(d_points, (affine_mem*)ctx->lam.p, n, st), "glv expand");
     const affine_mem* lam = (const affine_mem*)ctx->lam.p;
-    int c, W;
     if (path == 1) {
-        MsmPlan pl = plan_msm(n2, ctx->forced_c);
-        c = pl.c;
-        W = pl.W;
+        MsmPlan pl = plan_msm(n2, forced_c);
+        *c_out = pl.c;
+        *W_out = pl.W;
         if (msm_slice_lds_bytes(pl.c, pl.M, pl.T) > 64 * 1024) {
             set_error_msg("msm plan exceeds LDS");
             return BP_EINVAL;
@@ -186,9 +179,10 @@ int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scal
                "slice");
         HIPCHK(launch_msm_reduce_slices((const xyzz*)ctx->partial.p, pl.S, pl.W, (xyzz*)ctx->wsum.p, st), "reduce");
     } else {
-        SortedPlan pl = plan_msm_sorted(n2, ctx->forced_c);
-        c = pl.c;
-        W = pl.W;
+        SortedPlan pl = plan_msm_sorted(n2, forced_c);
+        *c_out = pl.c;
+        *W_out = pl.W;
+        const int W = pl.W;
         const size_t NB = pl.NB;
         const size_t nout = ((size_t)1 << pl.lo_bits) + (NB >> pl.lo_bits);
         if ((rc = ctx->digits.reserve((size_t)W * pl.npad * sizeof(int16_t))) != BP_OK) return rc;
@@ -209,6 +203,26 @@ int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scal
         HIPCHK(launch_glv_digits(d_scalars_be, n, pl.npad, pl.c, pl.W, (int16_t*)ctx->digits.p, st), "digits");
         HIPCHK(launch_msm_sorted(d_points, lam, n, (const int16_t*)ctx->digits.p, n2, pl, b, (xyzz*)ctx->wsum.p, st), "sorted msm");
     }
+    return BP_OK;
+}
+
+// out = init + sum scalars[i] * points[i]; d_points (limb form) and d_scalars_be on device.
+// Leaves the result in ctx->d_result (limb form) and ctx->d_result_be; does not synchronise.
+int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scalars_be, size_t n, const affine_mem* d_init) {
+    hipStream_t st = ctx->stream;
+    int rc;
+    if ((rc = ctx->wsum.reserve(72 * sizeof(xyzz))) != BP_OK) return rc;
+    if ((rc = ctx->result.reserve(sizeof(affine_mem) + 64)) != BP_OK) return rc;
+    affine_mem* d_res = (affine_mem*)ctx->result.p;
+    uint8_t* d_res_be = (uint8_t*)ctx->result.p + sizeof(affine_mem);
+    if (n == 0) {
+        // empty sum: result = init (or infinity)
+        HIPCHK(hipMemsetAsync(ctx->wsum.p, 0, sizeof(xyzz), st), "memset");
+        HIPCHK(launch_msm_horner((const xyzz*)ctx->wsum.p, 1, 1, d_init, d_res, d_res_be, st), "horner");
+        return BP_OK;
+    }
+    int c = 0, W = 0;
+    if ((rc = msm_windows_on_device(ctx, d_points, d_scalars_be, n, 0, &c, &W)) != BP_OK) return rc;
     HIPCHK(launch_msm_horner((const xyzz*)ctx->wsum.p, W, c, d_init, d_res, d_res_be, st), "horner");
     return BP_OK;
 }
@@ -318,6 +332,76 @@ int bp_msm_device(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be
     const affine_mem* d_init;
     if ((rc = upload_init(ctx, init_xy, &d_init)) != BP_OK) return rc;
     if ((rc = msm_on_device(ctx, (const affine_mem*)ctx->points.p, (const uint8_t*)d_scalars_be, n, d_init)) != BP_OK) return rc;
+    return msm_fetch_result(ctx, out_xy);
+}
+
+int bp_msm_auto_window(size_t n) { return n ? plan_msm_sorted(2 * n, 0).c : 0; }
+
+size_t bp_msm_partial_bytes(int c) { return (c >= 2 && c <= 15) ? (size_t)glv_windows(c) * sizeof(xyzz) : 0; }
+
+int bp_msm_partial_device(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be, size_t n, int c, uint8_t* partial_out) {
+    if (!ctx || !partial_out || c < 2 || c > 15 || (n && (!d_points_xy || !d_scalars_be))) return BP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t bytes = bp_msm_partial_bytes(c);
+    if (n == 0) {  // empty shard: every window sum is the identity (ZZ = 0)
+        xyzz inf = xyzz_inf();
+        for (int w = 0; w < glv_windows(c); w++) memcpy(partial_out + (size_t)w * sizeof(xyzz), &inf, sizeof(xyzz));
+        return BP_OK;
+    }
+    HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream), "memset err");
+    int rc;
+    if ((rc = ctx->points.reserve(n * sizeof(affine_mem))) != BP_OK) return rc;
+    HIPCHK(launch_ingest_points((const uint8_t*)d_points_xy, (affine_mem*)ctx->points.p, n, ctx->d_err, ctx->stream), "ingest");
+    int cu = 0, W = 0;
+    if ((rc = msm_windows_on_device(ctx, (const affine_mem*)ctx->points.p, (const uint8_t*)d_scalars_be, n, c, &cu, &W)) != BP_OK) return rc;
+    int h_err = 0;
+    HIPCHK(hipMemcpyAsync(partial_out, ctx->wsum.p, bytes, hipMemcpyDeviceToHost, ctx->stream), "memcpy partial");
+    HIPCHK(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), "memcpy err");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "sync");
+    if (h_err) {
+        set_error_msg("input point not on curve");
+        return BP_EPOINT;
+    }
+    return BP_OK;
+}
+
+int bp_msm_partial(bp_ctx* ctx, const uint8_t* points_xy, const uint8_t* scalars_be, size_t n, int c, uint8_t* partial_out) {
+    if (!ctx || !partial_out || (n && (!points_xy || !scalars_be))) return BP_EINVAL;
+    void *d_pts = nullptr, *d_sc = nullptr;
+    if (n) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+        int rc;
+        if ((rc = ctx->in_points_be.reserve(n * 64)) != BP_OK) return rc;
+        if ((rc = ctx->in_scalars_be.reserve(n * 32)) != BP_OK) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->in_points_be.p, points_xy, n * 64, hipMemcpyHostToDevice, ctx->stream), "memcpy points");
+        HIPCHK(hipMemcpyAsync(ctx->in_scalars_be.p, scalars_be, n * 32, hipMemcpyHostToDevice, ctx->stream), "memcpy scalars");
+        d_pts = ctx->in_points_be.p;
+        d_sc = ctx->in_scalars_be.p;
+    }
+    return bp_msm_partial_device(ctx, d_pts, d_sc, n, c, partial_out);
+}
+
+int bp_msm_combine(bp_ctx* ctx, const uint8_t* partials, size_t nparts, int c, const uint8_t* init_xy, uint8_t out_xy[64]) {
+    if (!ctx || !out_xy || c < 2 || c > 15 || (nparts && !partials) || nparts > 4096) return BP_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    const int W = glv_windows(c);
+    int rc;
+    if ((rc = ctx->wsum.reserve(72 * sizeof(xyzz))) != BP_OK) return rc;
+    if ((rc = ctx->result.reserve(sizeof(affine_mem) + 64)) != BP_OK) return rc;
+    if ((rc = ctx->partial.reserve((nparts ? nparts : 1) * (size_t)W * sizeof(xyzz))) != BP_OK) return rc;
+    HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream), "memset err");
+    const affine_mem* d_init;
+    if ((rc = upload_init(ctx, init_xy, &d_init)) != BP_OK) return rc;
+    if (nparts)
+        HIPCHK(hipMemcpyAsync(ctx->partial.p, partials, nparts * (size_t)W * sizeof(xyzz), hipMemcpyHostToDevice, ctx->stream), "memcpy partials");
+    // partial[g][w] -> wsum[w]: the slice reduction kernel with "slices" strided by W
+    HIPCHK(launch_msm_reduce_parts((const xyzz*)ctx->partial.p, (int)nparts, W, (xyzz*)ctx->wsum.p, ctx->stream), "reduce parts");
+    HIPCHK(launch_msm_horner((const xyzz*)ctx->wsum.p, W, c, d_init, (affine_mem*)ctx->result.p, (uint8_t*)ctx->result.p + sizeof(affine_mem),
+                             ctx->stream),
+           "horner");
     return msm_fetch_result(ctx, out_xy);
 }
 

@@ -19,6 +19,7 @@ hipError_t launch_glv_digits(const uint8_t* scalars_be, size_t n, size_t npad, i
 hipError_t launch_msm_slice(const affine_mem* pts, const affine_mem* lam, size_t n1, const int16_t* digits, size_t n, size_t npad, int M, int c,
                             int W, int S, int T, xyzz* partial, hipStream_t st);
 hipError_t launch_msm_reduce_slices(const xyzz* partial, int S, int W, xyzz* wsum, hipStream_t st);
+hipError_t launch_msm_reduce_parts(const xyzz* parts, int G, int W, xyzz* wsum, hipStream_t st);
 hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine_mem* init, affine_mem* out_limbs, uint8_t* out_be, hipStream_t st);
 
 

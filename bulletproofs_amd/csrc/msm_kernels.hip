@@ -288,6 +288,29 @@ __global__ __launch_bounds__(64) void k_msm_reduce_slices(const xyzz* __restrict
     if (tid == 0) wsum[w] = red[0];
 }
 
+// wsum[w] = sum over parts g of parts[g][w] (multi-GPU combine: one part per rank); one 64-lane workgroup per window.
+__global__ __launch_bounds__(64) void k_msm_reduce_parts(const xyzz* __restrict__ parts, int G, int W, xyzz* __restrict__ wsum) {
+    __shared__ xyzz red[64];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    xyzz acc = xyzz_inf();
+    for (int g = tid; g < G; g += 64) {
+        xyzz o = parts[(size_t)g * W + w];
+        if (!fp_raw_is_zero(o.ZZ)) xyzz_add(acc, o);
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int off = 32; off >= 1; off >>= 1) {
+        if (tid < off) {
+            xyzz v = red[tid];
+            xyzz o = red[tid + off];
+            xyzz_add(v, o);
+            red[tid] = v;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) wsum[w] = red[0];
+}
+
 // result = init + sum_w 2^(c*w) wsum[w]  (Horner, one lane: the doubling chain is inherently serial),
 // normalised to the canonical affine element and written as 64 big-endian bytes.
 __global__ void k_msm_horner(const xyzz* __restrict__ wsum, int W, int c, const affine_mem* __restrict__ init, affine_mem* __restrict__ out_limbs,
@@ -356,6 +379,10 @@ hipError_t launch_msm_slice(const affine_mem* pts, const affine_mem* lam, size_t
 }
 hipError_t launch_msm_reduce_slices(const xyzz* partial, int S, int W, xyzz* wsum, hipStream_t st) {
     hipLaunchKernelGGL(k_msm_reduce_slices, dim3((unsigned)W), dim3(64), 0, st, partial, S, wsum);
+    return hipGetLastError();
+}
+hipError_t launch_msm_reduce_parts(const xyzz* parts, int G, int W, xyzz* wsum, hipStream_t st) {
+    hipLaunchKernelGGL(k_msm_reduce_parts, dim3((unsigned)W), dim3(64), 0, st, parts, G, W, wsum);
     return hipGetLastError();
 }
 hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine_mem* init, affine_mem* out_limbs, uint8_t* out_be, hipStream_t st) {

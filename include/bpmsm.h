@@ -65,6 +65,21 @@ int bp_msm(bp_ctx* ctx, const uint8_t* points_xy, const uint8_t* scalars_be, siz
  * throughput benchmark times (inputs resident, see bench.py). */
 int bp_msm_device(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be, size_t n, const uint8_t* init_xy, uint8_t out_xy[64]);
 
+/* One large MSM across several GPUs (one process per GPU, points sharded; SURVEY.md 8e mode ii).
+ * No counterpart in the reference (single-threaded CPU); this is the exchange step of the batch layer:
+ *   c = bp_msm_auto_window(shard_size)              same value on every rank (call with the largest shard)
+ *   bp_msm_partial_device(...)                      rank-local window sums  sum_i digit_w(k_i) * P_i,
+ *                                                   bp_msm_partial_bytes(c) opaque bytes (W window sums)
+ *   all-gather the partials (RCCL / any transport; EC addition is not a reduction operator)
+ *   bp_msm_combine(partials of all ranks)           per-window sum over the ranks + ONE Horner combine
+ * d_points_xy / d_scalars_be are DEVICE pointers as in bp_msm_device; partial_out / partials are host
+ * buffers.  The result equals bp_msm over the concatenated inputs, bit for bit. */
+int bp_msm_auto_window(size_t n);
+size_t bp_msm_partial_bytes(int c);
+int bp_msm_partial_device(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be, size_t n, int c, uint8_t* partial_out);
+int bp_msm_partial(bp_ctx* ctx, const uint8_t* points_xy, const uint8_t* scalars_be, size_t n, int c, uint8_t* partial_out); /* host inputs */
+int bp_msm_combine(bp_ctx* ctx, const uint8_t* partials, size_t nparts, int c, const uint8_t* init_xy, uint8_t out_xy[64]);
+
 /* Testing / tuning knob: force the Pippenger window width (0 = automatic). */
 void bp_msm_set_window(bp_ctx* ctx, int c);
 /* Testing / tuning knob: 0 = automatic, 1 = LDS slice path (small / medium n), 2 = global sorted

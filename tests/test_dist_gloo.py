@@ -54,12 +54,17 @@ def _worker(rank, world, port, q):
     pts = [ec.mul(ec.G, rng.randrange(1, ec.Q)) for _ in range(11)]
     ks = [rng.randrange(ec.Q) for _ in range(11)]
 
-    def msm_fn(pb, sb):
-        pp = [ec.dec64(pb[i:i + 64]) for i in range(0, len(pb), 64)]
-        kk = [int.from_bytes(sb[i:i + 32], "big") for i in range(0, len(sb), 32)]
-        return ec.enc64(ec.msm_naive(pp, kk, None))
+    # stand-ins with the shapes of ctx.msm_partial_device / ctx.msm_combine: a "partial" here is one encoded point
+    def partial_fn(lo_, hi_):
+        return ec.enc64(ec.msm_naive(pts[lo_:hi_], ks[lo_:hi_], None))
 
-    msm_got = batch.msm_sharded(msm_fn, b"".join(ec.enc64(p) for p in pts), b"".join(k.to_bytes(32, "big") for k in ks))
+    def combine_fn(parts, g):
+        acc = None
+        for i in range(g):
+            acc = ec.add(acc, ec.dec64(parts[64 * i:64 * i + 64]))
+        return ec.enc64(acc)
+
+    msm_got = batch.msm_sharded(len(pts), partial_fn, combine_fn)
     msm_ok = msm_got == ec.enc64(ec.msm_naive(pts, ks, None))
     q.put((rank, got == want and msm_ok, hi - lo))
     dist.destroy_process_group()

@@ -186,3 +186,22 @@ def test_msm_batch_shared_generators(ctx, oracle_c):
         assert ctx.msm_batch(gens, []) == b""
     finally:
         gens.close()
+
+
+@pytest.mark.parametrize("shards", [[700], [300, 0, 399, 1], [1, 1, 1]])
+def test_msm_window_partials_combine(ctx, oracle_c, shards):
+    """Multi-GPU exchange step on one GPU: per-shard window partials (bp_msm_partial) combined by
+    bp_msm_combine equal the single MSM over the concatenated inputs, bit for bit (uneven and empty shards)."""
+    import bulletproofs_amd as bpa
+    n = sum(shards)
+    rng = random.Random(600 + n)
+    pts = _rand_points(rng, n, oracle_c)
+    ks = [rng.randrange(2**256) for _ in range(n)]
+    init = oracle_c.mul(ec.G, 99)
+    want = ec.enc64(oracle_c.msm_naive(pts, [k % ec.Q for k in ks], init))
+    c = bpa.msm_auto_window(max(shards))
+    parts, lo = b"", 0
+    for sz in shards:
+        parts += ctx.msm_partial(*_pack(pts[lo:lo + sz], ks[lo:lo + sz]), c)
+        lo += sz
+    assert ctx.msm_combine(parts, len(shards), c, ec.enc64(init)) == want
