@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256, 2) void k_mb_msm(size_t njobs, int np, const a
             const int16_t* dg = digF + job * (size_t)nfw;
             for (int idx = lane; idx < nfw; idx += MB_TP) {
                 int d = dg[idx];
+                if (d == -32768) d = 32768;  // c = 16: the digit +2^15 wraps in int16; -2^15 itself never occurs
                 if (d != 0) {
                     affine e = affine_load(table[(size_t)idx * NB + ((d < 0 ? -d : d) - 1)]);
                     if (d < 0) e.y = fp_neg(e.y);

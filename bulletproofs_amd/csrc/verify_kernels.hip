@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
         const int16_t* dg = digF + pr * (size_t)nfw;
         for (int idx = lane; idx < ((dbg_skip & 1) ? 0 : nfw); idx += TP) {
             int d = dg[idx];
+            if (d == -32768) d = 32768;  // c = 16: the digit +2^15 wraps in int16; -2^15 itself never occurs
             if (d != 0) {
                 affine e = affine_load(table[(size_t)idx * NB + ((d < 0 ? -d : d) - 1)]);
                 if (d < 0) e.y = fp_neg(e.y);

@@ -47,7 +47,7 @@ def test_bp_c2_n64_m16(ctx):
         gens.close()
 
 
-@pytest.mark.parametrize("window_bits", [4, 8, 10, 0])
+@pytest.mark.parametrize("window_bits", [4, 8, 10, 16, 0])
 def test_bp_c3_batch(ctx, window_bits):
     """256 distinct n=64 m=1 proofs sharing generators, with every 5th one tampered."""
     b = load("bp_c3_batch_n64_m1.json")
