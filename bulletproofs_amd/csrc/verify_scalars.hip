@@ -3,7 +3,7 @@
 // matches the parallelism each step really has (the reference does all of it on one thread):
 //
 //   k_bpv_hash1  4 lanes/proof   y = H(A,S), x = H(T1,T2,G,H), x_u = H(tau_x,miu,tx), c = H(A,S,T1,T2,G,H)
-//   k_bpv_fixmul 16 lanes/proof  y*G and x_u*G (:571, :588) from the generator table, 8 lanes each
+//   k_bpv_fixmul 4 lanes/proof   y*G and x_u*G (:571, :588) from the generator table, 2 lanes each
 //   k_bpv_fixinv 1 lane/proof    one shared field inversion -> affine yG, ux (needed as hash input)
 //   k_bpv_hash2  k+1 lanes/proof z = H(yG), x_j = H(L_j, R_j, ux)                         (:572, :656)
 //   k_bpv_consts 1 lane/proof    one batched inversion mod q for y, y-1, x_j; delta; scalars of
@@ -210,12 +210,16 @@ __device__ __forceinline__ void store_digits(const fq& kk, int c, int W, int16_t
     for (int w = 0; w < W; w++) out[w] = (int16_t)window_digit(kk, c, w, carry);
 }
 
-// y*G (lanes 0-7) and x_u*G (lanes 8-15) per proof: table gathers + mixed adds, 8-lane tree sum.
+// y*G and x_u*G per proof: table gathers + mixed adds.  FM_SUB lanes per multiplication (windows
+// dealt round-robin), 2*FM_SUB lanes per proof.  Two lanes each: with 16-bit windows a multiplication is
+// only 17 table additions, and every extra tree level costs a full XYZZ addition in all lanes
+// (8 lanes per multiplication spent 138M VALU instructions per 16384 proofs, mostly in the tree).
+#define FM_SUB 2
 __global__ __launch_bounds__(256) void k_bpv_fixmul(int k, int nm, size_t nproofs, const affine_mem* __restrict__ table, int c, int W,
                                                     const fq* __restrict__ chal, xyzz* __restrict__ fixres, const int* __restrict__ bad) {
     __shared__ xyzz red[256];
-    const int tid = threadIdx.x, lane = tid & 15, sub = lane & 7, which = lane >> 3;
-    const size_t pr = (size_t)blockIdx.x * 16 + (tid >> 4);
+    const int tid = threadIdx.x, lane = tid % (2 * FM_SUB), sub = lane % FM_SUB, which = lane / FM_SUB;
+    const size_t pr = (size_t)blockIdx.x * (256 / (2 * FM_SUB)) + tid / (2 * FM_SUB);
     const int NB = 1 << (c - 1);
     xyzz acc = xyzz_inf();
     if (pr < nproofs && !bad[pr]) {
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void k_bpv_fixmul(int k, int nm, size_t nproof
         uint32_t carry = 0;
         for (int w = 0; w < W; w++) {
             int d = window_digit(s, c, w, carry);
-            if ((w & 7) == sub && d != 0) {
+            if ((w % FM_SUB) == sub && d != 0) {
                 affine e = affine_load(table[(pG * W + w) * NB + ((d < 0 ? -d : d) - 1)]);
                 if (d < 0) e.y = fp_neg(e.y);
                 xyzz_madd(acc, e);
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256) void k_bpv_fixmul(int k, int nm, size_t nproof
     }
     red[tid] = acc;
     __syncthreads();
-    for (int off = 4; off >= 1; off >>= 1) {
+    for (int off = FM_SUB / 2; off >= 1; off >>= 1) {
         if (sub < off) {
             xyzz v = red[tid];
             xyzz o = red[tid + off];
@@ -452,7 +456,7 @@ hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, i
     const int nm = n_bits * m;
     hipLaunchKernelGGL(k_bpv_hash1, dim3((unsigned)((nproofs * 4 + 63) / 64)), dim3(64), 0, st, proofs, proof_len, k, m, nm, nproofs, pts, gens,
                        chal, bad);
-    hipLaunchKernelGGL(k_bpv_fixmul, dim3((unsigned)((nproofs + 15) / 16)), dim3(256), 0, st, k, nm, nproofs, table, c, W, chal, fixres, bad);
+    hipLaunchKernelGGL(k_bpv_fixmul, dim3((unsigned)((nproofs + 256 / (2 * FM_SUB) - 1) / (256 / (2 * FM_SUB)))), dim3(256), 0, st, k, nm, nproofs, table, c, W, chal, fixres, bad);
     hipLaunchKernelGGL(k_bpv_fixinv, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, nproofs, fixres, fixaff, bad);
     hipLaunchKernelGGL(k_bpv_hash2, dim3((unsigned)((nproofs * (k + 1) + 63) / 64)), dim3(64), 0, st, k, m, nproofs, pts, fixaff, chal, bad);
     hipLaunchKernelGGL(k_bpv_consts, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W,
