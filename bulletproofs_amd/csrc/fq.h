@@ -189,6 +189,199 @@ BP_HD_NOINLINE fq fq_mont_inv(fq a) {
 }
 BP_HD fq fq_inv(const fq& a) { return fq_from_mont(fq_mont_inv(fq_to_mont(a))); }
 
+// ---- reduced-radix Montgomery arithmetic mod q for the device-side scalar pipelines --------------
+// `fqm`: 9 limbs of 29 bits, Montgomery domain with R = 2^261, value kept < 2q ("weakly reduced").
+// The 8x32 CIOS product above compiles to ~500 VALU instructions (every partial product drags a 64-bit
+// carry addition); here a whole column (<= 18 products < 2^58) accumulates in one 64-bit register pair:
+// 81 + 81 v_mad_u64_u32, nine 32-bit multiplies for the quotient digits, one mask/shift per column.
+// Since R = 32 * 2^256 > 32 q, inputs < 2q give (ab + mq)/R < q/8 + q: no conditional subtraction
+// inside the product.
+struct fqm {
+    uint32_t v[9];
+};
+#define BP_FQM_Q                                                                                                        \
+    { 0x10364141u, 0x1e92f466u, 0x12280eefu, 0x1db9cd5eu, 0x1fffebaau, 0x1fffffffu, 0x1fffffffu, 0x1fffffffu, 0x00ffffffu }
+#define BP_FQM_2Q                                                                                                       \
+    { 0x006c8282u, 0x1d25e8cdu, 0x04501ddfu, 0x1b739abdu, 0x1fffd755u, 0x1fffffffu, 0x1fffffffu, 0x1fffffffu, 0x01ffffffu }
+#define BP_FQM_QINV 0x1588b13fu  // -q^-1 mod 2^29
+#define BP_M29Q 0x1FFFFFFFu
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BP_FQ_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define BP_FQ_OPAQUE(x) ((void)0)
+#endif
+
+BP_HD fqm fqm_one() {  // R mod q
+    fqm r = {{0x1937d7e0u, 0x0da1732fu, 0x1afe2201u, 0x08c6542du, 0x00028aa2u, 0, 0, 0, 0}};
+    return r;
+}
+BP_HD fqm fqm_zero() {
+    fqm r = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    return r;
+}
+
+// v >= K ? v - K : v   (limbs of v and K normalised: < 2^29, top limb free)
+BP_HD void fqm_csub(uint32_t v[9], const uint32_t K[9]) {
+    uint32_t t[9];
+    int32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int32_t d = (int32_t)v[i] - (int32_t)K[i] + borrow;
+        t[i] = (uint32_t)d & BP_M29Q;
+        borrow = d >> 29;
+    }
+    int32_t d = (int32_t)v[8] - (int32_t)K[8] + borrow;
+    if (d >= 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = t[i];
+        v[8] = (uint32_t)d;
+    }
+}
+
+BP_HD fqm fqm_mul(fqm a, fqm b) {
+    uint32_t q[9] = BP_FQM_Q;
+    uint32_t qinv = BP_FQM_QINV;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        BP_FQ_OPAQUE(a.v[i]);
+        BP_FQ_OPAQUE(b.v[i]);
+        BP_FQ_OPAQUE(q[i]);  // keep the multiplier: q's limbs 2^29 - 1 would otherwise become 64-bit shift/subtract pairs
+    }
+    BP_FQ_OPAQUE(qinv);
+    uint32_t m[9];
+    fqm r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * q[k - i];
+        m[k] = ((uint32_t)acc * qinv) & BP_M29Q;
+        BP_FQ_OPAQUE(m[k]);
+        acc += (uint64_t)m[k] * q[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) {
+            acc += (uint64_t)a.v[i] * b.v[k - i];
+            acc += (uint64_t)m[i] * q[k - i];
+        }
+        r.v[k - 9] = (uint32_t)acc & BP_M29Q;
+        acc >>= 29;
+    }
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
+BP_HD fqm fqm_sqr_n(fqm a, int n) {
+    for (int i = 0; i < n; i++) a = fqm_mul(a, a);
+    return a;
+}
+
+// a + b, a - b: inputs < 2q, result < 2q
+BP_HD fqm fqm_add(const fqm& a, const fqm& b) {
+    const uint32_t q2[9] = BP_FQM_2Q;
+    fqm r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t t = a.v[i] + b.v[i] + c;
+        r.v[i] = t & BP_M29Q;
+        c = t >> 29;
+    }
+    r.v[8] = a.v[8] + b.v[8] + c;
+    fqm_csub(r.v, q2);
+    return r;
+}
+BP_HD fqm fqm_sub(const fqm& a, const fqm& b) {
+    const uint32_t q2[9] = BP_FQM_2Q;
+    fqm r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int32_t t = (int32_t)a.v[i] + (int32_t)q2[i] - (int32_t)b.v[i] + c;
+        r.v[i] = (uint32_t)t & BP_M29Q;
+        c = t >> 29;
+    }
+    r.v[8] = (uint32_t)((int32_t)a.v[8] + (int32_t)q2[8] - (int32_t)b.v[8] + c);
+    fqm_csub(r.v, q2);
+    return r;
+}
+BP_HD fqm fqm_neg(const fqm& a) { return fqm_sub(fqm_zero(), a); }
+
+// plain fq (canonical, < q) -> Montgomery domain, and back to the canonical plain value
+BP_HD fqm fqm_from_fq(const fq& a) {
+    const uint32_t* w = a.v;
+    fqm t;
+    t.v[0] = w[0] & BP_M29Q;
+    t.v[1] = ((w[0] >> 29) | (w[1] << 3)) & BP_M29Q;
+    t.v[2] = ((w[1] >> 26) | (w[2] << 6)) & BP_M29Q;
+    t.v[3] = ((w[2] >> 23) | (w[3] << 9)) & BP_M29Q;
+    t.v[4] = ((w[3] >> 20) | (w[4] << 12)) & BP_M29Q;
+    t.v[5] = ((w[4] >> 17) | (w[5] << 15)) & BP_M29Q;
+    t.v[6] = ((w[5] >> 14) | (w[6] << 18)) & BP_M29Q;
+    t.v[7] = ((w[6] >> 11) | (w[7] << 21)) & BP_M29Q;
+    t.v[8] = w[7] >> 8;
+    const fqm r2 = {{0x09f6ab4bu, 0x1f300d1eu, 0x1c0bd5d8u, 0x0c8ada8cu, 0x11cefa2bu, 0x08b79a0fu, 0x1e697f5eu, 0x00e34de2u, 0x009c7356u}};
+    return fqm_mul(t, r2);
+}
+BP_HD fq fqm_to_fq(const fqm& a) {
+    fqm u = fqm_zero();
+    u.v[0] = 1;
+    fqm c = fqm_mul(a, u);  // a / R  < q + 1
+    const uint32_t q[9] = BP_FQM_Q;
+    fqm_csub(c.v, q);
+    const uint32_t* v = c.v;
+    fq s;
+    s.v[0] = v[0] | (v[1] << 29);
+    s.v[1] = (v[1] >> 3) | (v[2] << 26);
+    s.v[2] = (v[2] >> 6) | (v[3] << 23);
+    s.v[3] = (v[3] >> 9) | (v[4] << 20);
+    s.v[4] = (v[4] >> 12) | (v[5] << 17);
+    s.v[5] = (v[5] >> 15) | (v[6] << 14);
+    s.v[6] = (v[6] >> 18) | (v[7] << 11);
+    s.v[7] = (v[7] >> 21) | (v[8] << 8);
+    return s;
+}
+// value == 0 mod q ?  (weakly reduced: 0 or q)
+BP_HD bool fqm_is_zero(const fqm& a) {
+    const uint32_t q[9] = BP_FQM_Q;
+    uint32_t z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        z |= a.v[i];
+        e |= a.v[i] ^ q[i];
+    }
+    return z == 0 || e == 0;
+}
+
+// a^(q-2), same exponent schedule as fq_mont_inv
+BP_HD_NOINLINE fqm fqm_inv(fqm a) {
+    const uint8_t nsqr[26] = {5, 3, 4, 4, 5, 2, 5, 6, 5, 4, 3, 6, 10, 4, 5, 4, 5, 6, 4, 5, 6, 10, 4, 9, 4, 1};
+    const uint8_t odd[26] = {11, 5, 5, 7, 13, 3, 7, 13, 11, 13, 1, 5, 7, 7, 15, 15, 9, 11, 13, 3, 13, 13, 9, 9, 15, 1};
+    fqm tbl[8];
+    tbl[0] = a;
+    fqm a2 = fqm_mul(a, a);
+    for (int i = 1; i < 8; i++) tbl[i] = fqm_mul(tbl[i - 1], a2);
+    fqm x3 = tbl[3];
+    fqm x6 = fqm_mul(fqm_sqr_n(x3, 3), x3);
+    fqm x12 = fqm_mul(fqm_sqr_n(x6, 6), x6);
+    fqm x24 = fqm_mul(fqm_sqr_n(x12, 12), x12);
+    fqm x48 = fqm_mul(fqm_sqr_n(x24, 24), x24);
+    fqm x96 = fqm_mul(fqm_sqr_n(x48, 48), x48);
+    fqm x120 = fqm_mul(fqm_sqr_n(x96, 24), x24);
+    fqm x126 = fqm_mul(fqm_sqr_n(x120, 6), x6);
+    fqm acc = fqm_mul(fqm_mul(x126, x126), a);
+    for (int s = 0; s < 26; s++) {
+        acc = fqm_sqr_n(acc, nsqr[s]);
+        acc = fqm_mul(acc, tbl[odd[s] >> 1]);
+    }
+    return acc;
+}
+
 // ---- GLV endomorphism split (secp256k1: lambda^3 = 1 mod q, phi(x, y) = (beta x, y) = lambda * (x, y)) ----
 // k = k1 + k2 * lambda (mod q) with |k1|, |k2| < 2^128 (constants and method of libsecp256k1's
 // scalar_split_lambda).  Halves the doubling chain of every variable-base multiplication.

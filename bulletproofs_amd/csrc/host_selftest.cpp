@@ -25,6 +25,24 @@ void bpt_fq_add(uint8_t* out, const uint8_t* a, const uint8_t* b) { fq_to_be(out
 void bpt_fq_sub(uint8_t* out, const uint8_t* a, const uint8_t* b) { fq_to_be(out, fq_sub(fq_from_be_raw(a), fq_from_be_raw(b))); }
 void bpt_fq_inv(uint8_t* out, const uint8_t* a) { fq_to_be(out, fq_inv(fq_from_be_raw(a))); }
 // GLV split: k1, k2 magnitudes (32 B BE each) and sign flags (bit 0: k1 negative, bit 1: k2 negative)
+// reduced-radix Montgomery domain: (a*b), (a+b), (a-b), a^-1 computed through fqm and converted back
+void bpt_fqm_mul(uint8_t* out, const uint8_t* a, const uint8_t* b) {
+    fq_to_be(out, fqm_to_fq(fqm_mul(fqm_from_fq(fq_from_be_raw(a)), fqm_from_fq(fq_from_be_raw(b)))));
+}
+void bpt_fqm_add(uint8_t* out, const uint8_t* a, const uint8_t* b) {
+    fq_to_be(out, fqm_to_fq(fqm_add(fqm_from_fq(fq_from_be_raw(a)), fqm_from_fq(fq_from_be_raw(b)))));
+}
+void bpt_fqm_sub(uint8_t* out, const uint8_t* a, const uint8_t* b) {
+    fq_to_be(out, fqm_to_fq(fqm_sub(fqm_from_fq(fq_from_be_raw(a)), fqm_from_fq(fq_from_be_raw(b)))));
+}
+void bpt_fqm_inv(uint8_t* out, const uint8_t* a) { fq_to_be(out, fqm_to_fq(fqm_inv(fqm_from_fq(fq_from_be_raw(a))))); }
+// ((a - b) * (a + b) + a) * b - a : chains of lazily reduced values
+void bpt_fqm_chain(uint8_t* out, const uint8_t* a, const uint8_t* b) {
+    fqm x = fqm_from_fq(fq_from_be_raw(a)), y = fqm_from_fq(fq_from_be_raw(b));
+    fqm t = fqm_sub(fqm_mul(fqm_add(fqm_mul(fqm_sub(x, y), fqm_add(x, y)), x), y), x);
+    out[32] = fqm_is_zero(t) ? 1 : 0;
+    fq_to_be(out, fqm_to_fq(t));
+}
 int bpt_fq_glv(uint8_t* k1, uint8_t* k2, const uint8_t* k) {
     fq a, b;
     bool n1, n2;

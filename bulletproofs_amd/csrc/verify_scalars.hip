@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64) void k_bpv_hash2(int k, int m, size_t nproofs, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-proof constants for k_bpv_vec (Montgomery domain)
+// per-proof constants for k_bpv_vec (fqm: reduced-radix Montgomery domain, fq.h)
 #define CS_Z 0
 #define CS_A 1
 #define CS_B 2
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64) void k_bpv_hash2(int k, int m, size_t nproofs, 
 
 __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
                                                    const fq* __restrict__ chal, int c, int W, int16_t* __restrict__ digF, fq* __restrict__ varS,
-                                                   fq* __restrict__ cst, int* __restrict__ bad) {
+                                                   fqm* __restrict__ cst, int* __restrict__ bad) {
     size_t pr = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (pr >= nproofs || bad[pr]) return;
     const int nm = n_bits * m;
@@ -322,90 +322,90 @@ __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ p
     const uint8_t* sc = pf + PF_SCALARS;
     const uint8_t* ab = pf + PF_AB(k);
     const fq* ch = chal + pr * CH_COUNT(k);
-    fq* cs = cst + pr * CS_COUNT(k, m);
+    fqm* cs = cst + pr * CS_COUNT(k, m);
     fq* vs = varS + pr * (size_t)NV;
-    const fq ONE = fq_mont_one();
+    const fqm ONE = fqm_one();
 
     fq y = ch[CH_Y];
-    fq y_m = fq_to_mont(y), z_m = fq_to_mont(ch[CH_Z]), x_m = fq_to_mont(ch[CH_X]), xu_m = fq_to_mont(ch[CH_XU]), c_m = fq_to_mont(ch[CH_C]);
-    fq taux_m = fq_to_mont(fq_from_be_reduce(sc)), miu_m = fq_to_mont(fq_from_be_reduce(sc + 32)), tx_m = fq_to_mont(fq_from_be_reduce(sc + 64));
-    fq a_m = fq_to_mont(fq_from_be_reduce(ab)), b_m = fq_to_mont(fq_from_be_reduce(ab + 32));
+    fqm y_m = fqm_from_fq(y), z_m = fqm_from_fq(ch[CH_Z]), x_m = fqm_from_fq(ch[CH_X]), xu_m = fqm_from_fq(ch[CH_XU]), c_m = fqm_from_fq(ch[CH_C]);
+    fqm taux_m = fqm_from_fq(fq_from_be_reduce(sc)), miu_m = fqm_from_fq(fq_from_be_reduce(sc + 32)), tx_m = fqm_from_fq(fq_from_be_reduce(sc + 64));
+    fqm a_m = fqm_from_fq(fq_from_be_reduce(ab)), b_m = fqm_from_fq(fq_from_be_reduce(ab + 32));
 
     // batched inversion of (y, y - 1, x_0 .. x_{k-1}); a zero x_j / y is `.invert().unwrap()` panicking (:658, :569)
-    fq ym1 = fq_sub(y_m, ONE);
-    const bool y_is_one = fq_is_zero(ym1);
+    fqm ym1 = fqm_sub(y_m, ONE);
+    const bool y_is_one = fqm_is_zero(ym1);
     if (y_is_one) ym1 = ONE;
-    fq pref[BPV_MAXK + 2];
-    fq run = y_m;
+    fqm pref[BPV_MAXK + 2];
+    fqm run = y_m;
     pref[0] = run;
-    run = fq_mont_mul(run, ym1);
+    run = fqm_mul(run, ym1);
     pref[1] = run;
     bool zero_ch = fq_is_zero(y);
     for (int j = 0; j < k; j++) {
         fq xv = ch[CH_XJ + j];
         zero_ch = zero_ch || fq_is_zero(xv);
-        fq xm = fq_to_mont(xv);
+        fqm xm = fqm_from_fq(xv);
         cs[CS_XJ + j] = xm;
-        run = fq_mont_mul(run, xm);
+        run = fqm_mul(run, xm);
         pref[2 + j] = run;
     }
     if (zero_ch) {
         atomicOr(&bad[pr], 1);
         return;
     }
-    fq inv = fq_mont_inv(run);
+    fqm inv = fqm_inv(run);
     for (int j = k - 1; j >= 0; j--) {
-        fq xm = cs[CS_XJ + j];
-        fq xi = fq_mont_mul(inv, pref[1 + j]);
-        inv = fq_mont_mul(inv, xm);
+        fqm xm = cs[CS_XJ + j];
+        fqm xi = fqm_mul(inv, pref[1 + j]);
+        inv = fqm_mul(inv, xm);
         cs[CS_XINV(k) + j] = xi;
-        vs[1 + j] = fq_from_mont(fq_neg(fq_mont_mul(xm, xm)));      // L_j : -x_j^2     :665, 730
-        vs[1 + k + j] = fq_from_mont(fq_neg(fq_mont_mul(xi, xi)));  // R_j : -x_j^-2    :666, 731
+        vs[1 + j] = fqm_to_fq(fqm_neg(fqm_mul(xm, xm)));      // L_j : -x_j^2     :665, 730
+        vs[1 + k + j] = fqm_to_fq(fqm_neg(fqm_mul(xi, xi)));  // R_j : -x_j^-2    :666, 731
     }
-    fq ym1inv = fq_mont_mul(inv, pref[0]);
-    fq yinv_m = fq_mont_mul(inv, ym1);
+    fqm ym1inv = fqm_mul(inv, pref[0]);
+    fqm yinv_m = fqm_mul(inv, ym1);
     // y^-(2^t), y^nm
-    fq yp = yinv_m, ynm = y_m;
+    fqm yp = yinv_m, ynm = y_m;
     for (int t = 0; t < k; t++) {
         cs[CS_YINVP(k) + t] = yp;
-        yp = fq_mont_mul(yp, yp);
-        ynm = fq_mont_mul(ynm, ynm);
+        yp = fqm_mul(yp, yp);
+        ynm = fqm_mul(ynm, ynm);
     }
     // sum_{i<nm} y^i = (y^nm - 1)/(y - 1)   (nm if y == 1)                    :606-609
-    fq sum_y;
+    fqm sum_y;
     if (y_is_one) {
         fq t = fq_zero();
         t.v[0] = (uint32_t)nm;
-        sum_y = fq_to_mont(t);
+        sum_y = fqm_from_fq(t);
     } else {
-        sum_y = fq_mont_mul(fq_sub(ynm, ONE), ym1inv);
+        sum_y = fqm_mul(fqm_sub(ynm, ONE), ym1inv);
     }
     // z^(2+j); sum_d = (2^n - 1) sum_j z^(2+j)                                 :597-599, 621-636
-    fq zsq = fq_mont_mul(z_m, z_m);
-    fq zp = zsq, sum_z = fq_zero();
+    fqm zsq = fqm_mul(z_m, z_m);
+    fqm zp = zsq, sum_z = fqm_zero();
     for (int j = 0; j < m; j++) {
         cs[CS_ZPOW(k) + j] = zp;
-        sum_z = fq_add(sum_z, zp);
-        vs[1 + 2 * k + j] = fq_from_mont(fq_mont_mul(c_m, zp));    // V_j : c z^(2+j)  :734-736
-        zp = fq_mont_mul(zp, z_m);
+        sum_z = fqm_add(sum_z, zp);
+        vs[1 + 2 * k + j] = fqm_to_fq(fqm_mul(c_m, zp));    // V_j : c z^(2+j)  :734-736
+        zp = fqm_mul(zp, z_m);
     }
     fq two_n = fq_zero();  // 2^n - 1 as a plain integer (n_bits <= 64 in every config; general for < 256)
     for (int b = 0; b < n_bits; b++) two_n.v[b >> 5] |= 1u << (b & 31);
-    fq sum_d = fq_mont_mul(fq_to_mont(two_n), sum_z);
+    fqm sum_d = fqm_mul(fqm_from_fq(two_n), sum_z);
     // delta = (z - z^2) sum_y - z sum_d                                        :639-642
-    fq delta = fq_sub(fq_mont_mul(fq_sub(z_m, zsq), sum_y), fq_mont_mul(sum_d, z_m));
+    fqm delta = fqm_sub(fqm_mul(fqm_sub(z_m, zsq), sum_y), fqm_mul(sum_d, z_m));
     // G : x_u (ab - tx) + c (delta - tx) ; H : miu - c tau_x                   :708-723
-    fq abm = fq_mont_mul(a_m, b_m);
-    fq sG = fq_add(fq_mont_mul(xu_m, fq_sub(abm, tx_m)), fq_mont_mul(c_m, fq_sub(delta, tx_m)));
-    fq sH = fq_sub(miu_m, fq_mont_mul(c_m, taux_m));
+    fqm abm = fqm_mul(a_m, b_m);
+    fqm sG = fqm_add(fqm_mul(xu_m, fqm_sub(abm, tx_m)), fqm_mul(c_m, fqm_sub(delta, tx_m)));
+    fqm sH = fqm_sub(miu_m, fqm_mul(c_m, taux_m));
     int16_t* dg = digF + pr * (size_t)(2 * nm + 2) * W;
-    store_digits(fq_from_mont(sG), c, W, dg + (size_t)(2 * nm) * W);
-    store_digits(fq_from_mont(sH), c, W, dg + (size_t)(2 * nm + 1) * W);
+    store_digits(fqm_to_fq(sG), c, W, dg + (size_t)(2 * nm) * W);
+    store_digits(fqm_to_fq(sH), c, W, dg + (size_t)(2 * nm + 1) * W);
     // S : -x ; T1 : c x ; T2 : c x^2                                           :727, 739-740
-    vs[0] = fq_from_mont(fq_neg(x_m));
-    fq cx = fq_mont_mul(c_m, x_m);
-    vs[1 + 2 * k + m] = fq_from_mont(cx);
-    vs[2 + 2 * k + m] = fq_from_mont(fq_mont_mul(cx, x_m));
+    vs[0] = fqm_to_fq(fqm_neg(x_m));
+    fqm cx = fqm_mul(c_m, x_m);
+    vs[1 + 2 * k + m] = fqm_to_fq(cx);
+    vs[2 + 2 * k + m] = fqm_to_fq(fqm_mul(cx, x_m));
     cs[CS_Z] = z_m;
     cs[CS_A] = a_m;
     cs[CS_B] = b_m;
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ p
 
 // One lane per (proof, i): g_i : a s_i + z ; h_i : y^-i (b s_i^-1 - d_i) - z          :670-705
 // s_i = prod_t (bit_t(i) ? x_{k-1-t} : x_{k-1-t}^-1), s_i^-1 = s_{nm-1-i}; d_i = z^(2+i/n) 2^(i mod n).
-__global__ __launch_bounds__(256) void k_bpv_vec(int n_bits, int m, int k, size_t nproofs, const fq* __restrict__ cst, int c, int W,
+__global__ __launch_bounds__(256) void k_bpv_vec(int n_bits, int m, int k, size_t nproofs, const fqm* __restrict__ cst, int c, int W,
                                                  int16_t* __restrict__ digF, const int* __restrict__ bad) {
     const int nm = n_bits * m;
     size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -421,34 +421,35 @@ __global__ __launch_bounds__(256) void k_bpv_vec(int n_bits, int m, int k, size_
     size_t pr = gid / nm;
     int i = (int)(gid % nm);
     if (bad[pr]) return;
-    const fq* cs = cst + pr * CS_COUNT(k, m);
-    fq s = fq_mont_one(), sinv = s, yip = s;
+    const fqm* cs = cst + pr * CS_COUNT(k, m);
+    fqm s = fqm_one(), sinv = s, yip = s;
     for (int t = 0; t < k; t++) {
-        fq xm = cs[CS_XJ + (k - 1 - t)], xi = cs[CS_XINV(k) + (k - 1 - t)];
+        fqm xm = cs[CS_XJ + (k - 1 - t)], xi = cs[CS_XINV(k) + (k - 1 - t)];
         if ((i >> t) & 1) {
-            s = fq_mont_mul(s, xm);
-            sinv = fq_mont_mul(sinv, xi);
-            yip = fq_mont_mul(yip, cs[CS_YINVP(k) + t]);
+            s = fqm_mul(s, xm);
+            sinv = fqm_mul(sinv, xi);
+            yip = fqm_mul(yip, cs[CS_YINVP(k) + t]);
         } else {
-            s = fq_mont_mul(s, xi);
-            sinv = fq_mont_mul(sinv, xm);
+            s = fqm_mul(s, xi);
+            sinv = fqm_mul(sinv, xm);
         }
     }
-    fq z_m = cs[CS_Z];
-    fq gs = fq_add(fq_mont_mul(cs[CS_A], s), z_m);
+    fqm z_m = cs[CS_Z];
+    fqm gs = fqm_add(fqm_mul(cs[CS_A], s), z_m);
     fq two_r = fq_zero();
     int r = i % n_bits;
     two_r.v[r >> 5] = 1u << (r & 31);
-    fq d_i = fq_mont_mul(fq_to_mont(two_r), cs[CS_ZPOW(k) + i / n_bits]);
-    fq hs = fq_sub(fq_mont_mul(yip, fq_sub(fq_mont_mul(cs[CS_B], sinv), d_i)), z_m);
+    fqm d_i = fqm_mul(fqm_from_fq(two_r), cs[CS_ZPOW(k) + i / n_bits]);
+    fqm hs = fqm_sub(fqm_mul(yip, fqm_sub(fqm_mul(cs[CS_B], sinv), d_i)), z_m);
     int16_t* dg = digF + pr * (size_t)(2 * nm + 2) * W;
-    store_digits(fq_from_mont(gs), c, W, dg + (size_t)i * W);
-    store_digits(fq_from_mont(hs), c, W, dg + (size_t)(nm + i) * W);
+    store_digits(fqm_to_fq(gs), c, W, dg + (size_t)i * W);
+    store_digits(fqm_to_fq(hs), c, W, dg + (size_t)(nm + i) * W);
 }
 
 // ------------------------------------------------------------------------------------------------
 size_t bpv_chal_count(int k) { return CH_COUNT(k); }
-size_t bpv_cst_count(int k, int m) { return CS_COUNT(k, m); }
+// in units of sizeof(fq): the constants are stored as fqm (9 words)
+size_t bpv_cst_count(int k, int m) { return ((size_t)CS_COUNT(k, m) * sizeof(fqm) + sizeof(fq) - 1) / sizeof(fq); }
 
 hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
                                       const affine_mem* gens, const affine_mem* table, int c, int W, int16_t* digF, fq* varS, fq* chal,
@@ -460,8 +461,9 @@ hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, i
     hipLaunchKernelGGL(k_bpv_fixinv, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, nproofs, fixres, fixaff, bad);
     hipLaunchKernelGGL(k_bpv_hash2, dim3((unsigned)((nproofs * (k + 1) + 63) / 64)), dim3(64), 0, st, k, m, nproofs, pts, fixaff, chal, bad);
     hipLaunchKernelGGL(k_bpv_consts, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W,
-                       digF, varS, cst, bad);
-    hipLaunchKernelGGL(k_bpv_vec, dim3((unsigned)((nproofs * (size_t)nm + 255) / 256)), dim3(256), 0, st, n_bits, m, k, nproofs, cst, c, W, digF,
+                       digF, varS, reinterpret_cast<fqm*>(cst), bad);
+    hipLaunchKernelGGL(k_bpv_vec, dim3((unsigned)((nproofs * (size_t)nm + 255) / 256)), dim3(256), 0, st, n_bits, m, k, nproofs,
+                       reinterpret_cast<const fqm*>(cst), c, W, digF,
                        bad);
     return hipGetLastError();
 }

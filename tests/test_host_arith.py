@@ -66,6 +66,20 @@ def test_fq(L):
     for a in vals[:30]:
         if a:
             assert call1(L.bpt_fq_inv, a) == pow(a, -1, Q)
+    # reduced-radix Montgomery domain (fqm) used by the verifier's scalar kernels
+    edge = [0, 1, 2, Q - 1, Q - 2, (Q - 1) // 2, 2**255 % Q, 2**128, 2**29 - 1, 2**232]
+    vals = edge + [rng.randrange(Q) for _ in range(40)]
+    for a in vals:
+        for b in vals[:14]:
+            assert call2(L.bpt_fqm_mul, a, b) == a * b % Q
+            assert call2(L.bpt_fqm_add, a, b) == (a + b) % Q
+            assert call2(L.bpt_fqm_sub, a, b) == (a - b) % Q
+            o = ctypes.create_string_buffer(33)
+            L.bpt_fqm_chain(o, b32(a), b32(b))
+            want = (((a - b) * (a + b) + a) * b - a) % Q
+            assert int.from_bytes(o.raw[:32], "big") == want and o.raw[32] == (1 if want == 0 else 0)
+        if a:
+            assert call1(L.bpt_fqm_inv, a) == pow(a, -1, Q)
     assert call1(L.bpt_fq_reduce, 2**256 - 1) == (2**256 - 1) % Q
     assert call1(L.bpt_fq_reduce, Q) == 0
 
