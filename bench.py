@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--proofs-per-gpu", type=int, default=16384)
+    ap.add_argument("--proofs-per-gpu", type=int, default=65536)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per proof in k_bpv_msm (16/32/64)")
     ap.add_argument("--window-bits", type=int, default=0, help="fixed-base table window (0 = auto)")
     ap.add_argument("--workload", default="verify", choices=["verify", "msm", "prove"],

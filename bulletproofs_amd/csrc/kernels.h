@@ -34,7 +34,8 @@ struct SortedBufs {
     xyzz *Bk, *Pseg, *RC;
 };
 hipError_t launch_msm_sorted(const affine_mem* pts, const affine_mem* lam, size_t n1, const int16_t* digits, size_t n2, const SortedPlan& pl,
-                             const SortedBufs& b, xyzz* wsum, hipStream_t st);
+                             const SortedBufs& b, xyzz* wsum, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, int split_w,
+                             int* W_eff);
 
 // gens_kernels.hip
 hipError_t launch_gens_bases(const affine_mem* pts, int np, int c, int W, xyzz* bases, hipStream_t st);

@@ -115,11 +115,11 @@ __global__ __launch_bounds__(SRT_T) void k_srt_scatter(const int16_t* __restrict
 }
 
 __global__ __launch_bounds__(256, 2) void k_srt_acc(const affine_mem* __restrict__ pts, const affine_mem* __restrict__ lam, size_t n1,
-                                                    const uint2* __restrict__ ent, const uint32_t* __restrict__ bstart, size_t npad, int NB, int L, int nseg, int W,
-                                                    xyzz* __restrict__ Bk, xyzz* __restrict__ Pseg) {
+                                                    const uint2* __restrict__ ent, const uint32_t* __restrict__ bstart, size_t npad, int NB, int L, int nseg,
+                                                    int w0, int nw, xyzz* __restrict__ Bk, xyzz* __restrict__ Pseg) {
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int w = (int)(g / nseg), t = (int)(g % nseg);
-    if (w >= W) return;
+    const int w = w0 + (int)(g / nseg), t = (int)(g % nseg);
+    if (w >= w0 + nw) return;
     const uint32_t Nw = bstart[(size_t)w * (NB + 1) + NB];
     const uint32_t j0 = (uint32_t)t * L;
     if (j0 >= Nw) return;
@@ -156,11 +156,11 @@ __global__ __launch_bounds__(256, 2) void k_srt_acc(const affine_mem* __restrict
 // digit distributions: the short top window, +-1 / small scalars) are queued for k_srt_finalize_big
 // so that no lane runs a long serial chain of additions.
 #define SRT_BIG 16
-__global__ __launch_bounds__(256, 2) void k_srt_finalize(const uint32_t* __restrict__ bstart, int NB, int L, int nseg, int W,
+__global__ __launch_bounds__(256, 2) void k_srt_finalize(const uint32_t* __restrict__ bstart, int NB, int L, int nseg, int w0, int nw,
                                                          xyzz* __restrict__ Bk, const xyzz* __restrict__ Pseg, uint32_t* __restrict__ queue) {
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int w = (int)(g / NB), b = (int)(g % NB);
-    if (w >= W) return;
+    const int w = w0 + (int)(g / NB), b = (int)(g % NB);
+    if (w >= w0 + nw) return;
     const uint32_t s = bstart[(size_t)w * (NB + 1) + b], e = bstart[(size_t)w * (NB + 1) + b + 1];
     xyzz r = xyzz_inf();
     if (e > s) {
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void k_srt_finalize(const uint32_t* __restr
         const uint32_t t1 = (e + L - 1) / L;  // segments t0 .. t1-1 start inside [s, e)
         if (t1 > t0 + SRT_BIG) {
             uint32_t q = atomicAdd(&queue[0], 1u);
-            queue[1 + q] = (uint32_t)g;
+            queue[1 + q] = (uint32_t)w * (uint32_t)NB + (uint32_t)b;
             return;
         }
         if (s % L) r = Bk[(size_t)w * NB + b];
@@ -215,9 +215,9 @@ __global__ __launch_bounds__(256) void k_srt_finalize_big(const uint32_t* __rest
 }
 
 // one wave per output: o < LO -> C_o = sum_hi B[hi*LO + o];  o >= LO -> R_(o-LO) = sum_lo B[(o-LO)*LO + lo]
-__global__ __launch_bounds__(256) void k_srt_rowcol(const xyzz* __restrict__ Bk, int NB, int lo_bits, xyzz* __restrict__ RC) {
+__global__ __launch_bounds__(256) void k_srt_rowcol(const xyzz* __restrict__ Bk, int NB, int lo_bits, int w0, xyzz* __restrict__ RC) {
     __shared__ xyzz red[256];
-    const int tid = threadIdx.x, lane = tid & 63, w = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = w0 + blockIdx.y;
     const int LO = 1 << lo_bits, HI = NB >> lo_bits, nout = LO + HI;
     const int o = blockIdx.x * 4 + (tid >> 6);
     const xyzz* B = Bk + (size_t)w * NB;
@@ -248,9 +248,9 @@ __global__ __launch_bounds__(256) void k_srt_rowcol(const xyzz* __restrict__ Bk,
 }
 
 // wsum[w] = sum_{lo >= 1} suffixC[lo] + 2^lo_bits * sum_{hi >= 1} suffixR[hi] + suffixR[0];  LO + HI <= 256
-__global__ __launch_bounds__(256) void k_srt_window(const xyzz* __restrict__ RC, int NB, int lo_bits, xyzz* __restrict__ wsum) {
+__global__ __launch_bounds__(256) void k_srt_window(const xyzz* __restrict__ RC, int NB, int lo_bits, int w0, xyzz* __restrict__ wsum) {
     __shared__ xyzz red[256];
-    const int tid = threadIdx.x, w = blockIdx.x;
+    const int tid = threadIdx.x, w = w0 + blockIdx.x;
     const int LO = 1 << lo_bits, HI = NB >> lo_bits, nout = LO + HI;
     xyzz v = tid < nout ? RC[(size_t)w * nout + tid] : xyzz_inf();
     red[tid] = v;
@@ -288,8 +288,48 @@ __global__ __launch_bounds__(256) void k_srt_window(const xyzz* __restrict__ RC,
     if (tid == 0) wsum[w] = red[0];
 }
 
+// wsum[w_lo] = sum_{w_lo <= w < w_hi} 2^(c (w - w_lo)) wsum[w]: Horner over the top windows, one lane,
+// so that this serial chain can run on a second stream while the low windows are still accumulating.
+__global__ void k_srt_horner_part(xyzz* __restrict__ wsum, int w_lo, int w_hi, int c) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    xyzz acc = wsum[w_hi - 1];
+    for (int w = w_hi - 2; w >= w_lo; w--) {
+        acc = xyzz_dbl_n(acc, c);
+        xyzz o = wsum[w];
+        xyzz_add(acc, o);
+    }
+    wsum[w_lo] = acc;
+}
+
+// bucket accumulation + reduction of the windows [w0, w0 + nw) on stream st
+static void srt_acc_windows(const affine_mem* pts, const affine_mem* lam, size_t n1, const SortedPlan& pl, const SortedBufs& b, int w0, int nw,
+                            hipStream_t st) {
+    size_t nthr = (size_t)nw * pl.nseg;
+    hipLaunchKernelGGL(k_srt_acc, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, pts, lam, n1, b.ent, b.bstart, pl.npad, pl.NB, pl.L,
+                       pl.nseg, w0, nw, b.Bk, b.Pseg);
+}
+static hipError_t srt_reduce_windows(const SortedPlan& pl, const SortedBufs& b, int w0, int nw, uint32_t* queue, xyzz* wsum, hipStream_t st) {
+    const int NB = pl.NB;
+    hipError_t e = hipMemsetAsync(queue, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    size_t nthr = (size_t)nw * NB;
+    hipLaunchKernelGGL(k_srt_finalize, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, b.bstart, NB, pl.L, pl.nseg, w0, nw, b.Bk, b.Pseg,
+                       queue);
+    hipLaunchKernelGGL(k_srt_finalize_big, dim3(2048), dim3(256), 0, st, b.bstart, NB, pl.L, pl.nseg, b.Bk, b.Pseg, queue);
+    const int nout = (1 << pl.lo_bits) + (NB >> pl.lo_bits);
+    hipLaunchKernelGGL(k_srt_rowcol, dim3((unsigned)((nout + 3) / 4), (unsigned)nw), dim3(256), 0, st, b.Bk, NB, pl.lo_bits, w0, b.RC);
+    hipLaunchKernelGGL(k_srt_window, dim3((unsigned)nw), dim3(256), 0, st, b.RC, NB, pl.lo_bits, w0, wsum);
+    return hipGetLastError();
+}
+
+// Window sums of the sorted path.  With a second stream (st2 + events) and split_w > 0, the windows
+// [split_w, W) are accumulated first; their latency-bound tail (finalize, row/column sums, the window
+// scan and the Horner chain over them) then runs on st2 while the windows [0, split_w) accumulate on st.
+// On return (stream order of st) wsum[0 .. *W_eff) are the window sums to combine:
+// *W_eff = W without the split, split_w + 1 with it (wsum[split_w] = the combined top part).
 hipError_t launch_msm_sorted(const affine_mem* pts, const affine_mem* lam, size_t n1, const int16_t* digits, size_t n2, const SortedPlan& pl,
-                             const SortedBufs& b, xyzz* wsum, hipStream_t st) {
+                             const SortedBufs& b, xyzz* wsum, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, int split_w,
+                             int* W_eff) {
     const int NB = pl.NB, W = pl.W;
     const size_t lds = (size_t)NB * 4;
     dim3 gcw((unsigned)pl.nchunks, (unsigned)W);
@@ -297,17 +337,23 @@ hipError_t launch_msm_sorted(const affine_mem* pts, const affine_mem* lam, size_
     hipLaunchKernelGGL(k_srt_colscan, dim3((unsigned)((NB + 255) / 256), (unsigned)W), dim3(256), 0, st, b.cnt, pl.nchunks, NB, b.bstart);
     hipLaunchKernelGGL(k_srt_bstart, dim3((unsigned)W), dim3(SRT_T), 0, st, b.bstart, NB);
     hipLaunchKernelGGL(k_srt_scatter, gcw, dim3(SRT_T), lds, st, digits, n2, pl.npad, pl.CH, NB, b.cnt, b.bstart, b.ent);
-    size_t nthr = (size_t)W * pl.nseg;
-    hipLaunchKernelGGL(k_srt_acc, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, pts, lam, n1, b.ent, b.bstart, pl.npad, NB, pl.L,
-                       pl.nseg, W, b.Bk, b.Pseg);
-    nthr = (size_t)W * NB;
-    hipError_t e = hipMemsetAsync(b.queue, 0, sizeof(uint32_t), st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_srt_finalize, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, b.bstart, NB, pl.L, pl.nseg, W, b.Bk, b.Pseg, b.queue);
-    hipLaunchKernelGGL(k_srt_finalize_big, dim3(2048), dim3(256), 0, st, b.bstart, NB, pl.L, pl.nseg, b.Bk, b.Pseg, b.queue);
-    const int nout = (1 << pl.lo_bits) + (NB >> pl.lo_bits);
-    hipLaunchKernelGGL(k_srt_rowcol, dim3((unsigned)((nout + 3) / 4), (unsigned)W), dim3(256), 0, st, b.Bk, NB, pl.lo_bits, b.RC);
-    hipLaunchKernelGGL(k_srt_window, dim3((unsigned)W), dim3(256), 0, st, b.RC, NB, pl.lo_bits, wsum);
+    hipError_t e;
+    if (!st2 || split_w <= 0 || split_w >= W - 1) {
+        srt_acc_windows(pts, lam, n1, pl, b, 0, W, st);
+        *W_eff = W;
+        return srt_reduce_windows(pl, b, 0, W, b.queue, wsum, st);
+    }
+    uint32_t* queue2 = b.queue + ((size_t)W * NB + 1);
+    srt_acc_windows(pts, lam, n1, pl, b, split_w, W - split_w, st);
+    if ((e = hipEventRecord(ev_fork, st)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(st2, ev_fork, 0)) != hipSuccess) return e;
+    if ((e = srt_reduce_windows(pl, b, split_w, W - split_w, queue2, wsum, st2)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_srt_horner_part, dim3(1), dim3(64), 0, st2, wsum, split_w, W, pl.c);
+    if ((e = hipEventRecord(ev_join, st2)) != hipSuccess) return e;
+    srt_acc_windows(pts, lam, n1, pl, b, 0, split_w, st);
+    if ((e = srt_reduce_windows(pl, b, 0, split_w, b.queue, wsum, st)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(st, ev_join, 0)) != hipSuccess) return e;
+    *W_eff = split_w + 1;
     return hipGetLastError();
 }
 
