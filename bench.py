@@ -32,12 +32,13 @@ MAD32_PER_PROOF_TOTAL = 6.60e6      # + the two fixed-base multiplications y*G, 
 # v_mad_u64_u32 sustains 31.2e12 lane-results/s at 8 waves/SIMD (SURVEY's assumed quarter-rate
 # figure was 9.83e12; the measured one is the denominator used here).
 PEAK_MAD32_PER_S = 31.2e12
-# HBM-side traffic of one k_bpv_msm launch at the default configuration (16384 proofs, auto table window),
-# from the separate --pmc passes in profiles/r01_pmc_read.csv / r01_pmc_write.csv:
-# TCC_EA0_RDREQ 24.98e6 x 64 B x 2 (gfx950 tallies 128-B requests at 64 B) + TCC_EA0_WRREQ 6.07e6 x 64 B.
-# (64-B table gathers, not the calibrated 16-B/lane streaming pattern: an upper estimate.)  The kernel is
-# VALU-bound: 3.6 GB in 6.5 ms is 0.55 TB/s, 7 % of HBM peak.
-PMC_TRAFFIC_BYTES_DEFAULT = 24.98e6 * 64 * 2 + 6.07e6 * 64
+# HBM-side traffic of one k_bpv_msm launch at the default configuration (65536 proofs, auto lanes and table
+# window), from the separate --pmc passes in profiles/r01_pmc_read.csv / r01_pmc_write.csv:
+# TCC_EA0_RDREQ 157.93e6 x 64 B + TCC_EA0_WRREQ 25.62e6 x 64 B.  The reads are 64-byte gathers (table
+# entries), not the 16-B/lane streaming pattern the guide's x2 correction was calibrated on: RDREQ x 64 B
+# already equals the algorithmic gather bytes (2210 table entries x 64 B = 141 KB per proof + digits), so
+# no doubling is applied.  11.7 GB in 16.3 ms = 0.72 TB/s, 9 % of HBM peak: the kernel is VALU-bound.
+PMC_TRAFFIC_BYTES_DEFAULT = 157.93e6 * 64 + 25.62e6 * 64
 
 
 def parse():
@@ -347,7 +348,7 @@ def main():
                 "peak": PEAK_MAD32_PER_S / 1e12,
                 "unit": "TMAD32/s",
                 "frac": achieved / PEAK_MAD32_PER_S,
-                "traffic": PMC_TRAFFIC_BYTES_DEFAULT if (P == 16384 and not args.window_bits and not args.lanes) else None,
+                "traffic": PMC_TRAFFIC_BYTES_DEFAULT if (P == 65536 and not args.window_bits and not args.lanes) else None,
                 "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_*.csv)",
                 "algorithmic_mad32_per_proof": MAD32_PER_PROOF_MSM,
                 "proofs_per_launch": P,
