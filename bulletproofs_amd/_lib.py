@@ -18,6 +18,7 @@ EXPORTED_SYMBOLS = [
     "bp_msm_device",
     "bp_msm_set_window",
     "bp_msm_set_path",
+    "bp_proto_set_path",
     "bp_msm_batch",
     "bp_msm_auto_window",
     "bp_msm_partial_bytes",
@@ -84,6 +85,8 @@ def lib():
     L.bp_msm_set_window.restype = None
     L.bp_msm_set_path.argtypes = [vp, i32]
     L.bp_msm_set_path.restype = None
+    L.bp_proto_set_path.argtypes = [vp, i32]
+    L.bp_proto_set_path.restype = None
     L.bp_gens_create.argtypes = [vp, cp, cp, sz, cp, cp, i32, ctypes.POINTER(vp)]
     L.bp_gens_create.restype = i32
     L.bp_gens_destroy.argtypes = [vp]
@@ -180,6 +183,10 @@ class Context:
     def set_path(self, path):
         """0 = automatic, 1 = LDS slice path, 2 = global sorted path (testing / tuning)."""
         lib().bp_msm_set_path(self._h, path)
+
+    def set_proto_path(self, path):
+        """0 = generator MSMs of prove/verify from the fixed-base table (default), 1 = reference-structured rounds."""
+        lib().bp_proto_set_path(self._h, path)
 
     def msm(self, points_xy, scalars_be, init_xy=None):
         """out = init + sum scalars[i]*points[i]; bytes in, 64 bytes out (see include/bpmsm.h)."""

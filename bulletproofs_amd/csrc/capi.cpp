@@ -338,6 +338,9 @@ void bp_msm_set_window(bp_ctx* ctx, int c) {
 void bp_msm_set_path(bp_ctx* ctx, int path) {
     if (ctx) ctx->msm_path = (path == 1 || path == 2) ? path : 0;
 }
+void bp_proto_set_path(bp_ctx* ctx, int path) {
+    if (ctx) ctx->proto_path = path == 1 ? 1 : 0;
+}
 
 int bp_msm_device(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be, size_t n, const uint8_t* init_xy, uint8_t out_xy[64]) {
     if (!ctx || !out_xy || (n && (!d_points_xy || !d_scalars_be))) return BP_EINVAL;

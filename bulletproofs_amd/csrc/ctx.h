@@ -39,6 +39,7 @@ struct bp_ctx {
     int forced_c = 0;
     int msm_path = 0;  // 0 auto, 1 LDS slice path, 2 sorted path (bp_msm_set_path)
     int verify_lanes = 0;
+    int proto_path = 0;  // protocol layer: 0 = every generator MSM from the fixed-base table, 1 = reference-structured (bp_proto_set_path)
     // optional per-kernel timing (bp_profile_*): HIP events on this context's stream
     bool profiling = false;
     static const int kMaxProf = 8;
@@ -54,6 +55,9 @@ struct bp_ctx {
     bp::DevBuf scratch[8];
     bp::DevBuf vartab, fixres;
     bp::DevBuf proto[6];  // protocol layer (proto.cpp): folded bases, hi_tag, staging
+    bp::DevBuf fb[3];     // fixed-table MSM of the protocol layer (fbmsm.hip): inputs, digits, partials + output
+    void* h_pin = nullptr;  // pinned host staging for the protocol layer's small uploads / read-backs (grow-only)
+    size_t h_pin_cap = 0;
     void release_all() {
         in_points_be.release();
         in_scalars_be.release();
@@ -69,6 +73,10 @@ struct bp_ctx {
         vartab.release();
         fixres.release();
         for (auto& s : proto) s.release();
+        for (auto& s : fb) s.release();
+        if (h_pin) (void)hipHostFree(h_pin);
+        h_pin = nullptr;
+        h_pin_cap = 0;
     }
 };
 

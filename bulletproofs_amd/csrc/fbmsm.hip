@@ -1,0 +1,100 @@
+// Latency-oriented MSM over the resident generator table, for ONE or a few jobs at a time: the shape
+// of the prover (A, S, T1, T2, every L_j / R_j of the inner-product rounds:
+// /root/reference/src/proofs/range_proof.rs:93-122, 168-169; inner_product.rs:70-115;
+// weighted_inner_product.rs:103-154, 222-239) and of a single-proof verifier (range_proof.rs:742-774).
+//
+// bp_msm_batch's kernel gives 16 lanes to a job because it expects thousands of jobs.  The prover has
+// two jobs per round and waits for them, so here a job spreads over the whole chip:
+//   job j = sum over its SPARSE generator terms (gidx[t], scalar[t])  +  sum over its extra points
+//   k_fb_acc   grid (nblk + nxblk, njobs): blocks < nblk stride over the job's (term, window) items -
+//              one table gather + one mixed addition each, no doublings; blocks >= nblk multiply the
+//              job-specific points (GLV ladder, one lane each); LDS tree -> one XYZZ partial per block
+//   k_fb_final one block per job: sum of the partials, ONE inversion, canonical x||y bytes
+// The scalars of the generator terms arrive as window digits (k_mb_digits of msm_batch.hip).
+#include <hip/hip_runtime.h>
+
+#include "ec.h"
+#include "ecmul.h"
+#include "fq.h"
+#include "kernels.h"
+
+namespace bp {
+
+#define FB_T 256
+
+__device__ __forceinline__ xyzz fb_block_sum(xyzz acc, xyzz* red, int tid) {
+    red[tid] = acc;
+    __syncthreads();
+    for (int off = FB_T / 2; off >= 1; off >>= 1) {
+        if (tid < off) {
+            xyzz v = red[tid];
+            xyzz o = red[tid + off];
+            xyzz_add(v, o);
+            red[tid] = v;
+        }
+        __syncthreads();
+    }
+    return red[0];
+}
+
+__global__ __launch_bounds__(FB_T) void k_fb_acc(const affine_mem* __restrict__ table, int W, int NB, const int16_t* __restrict__ dig,
+                                                 const uint32_t* __restrict__ gidx, const uint32_t* __restrict__ toff,
+                                                 const affine_mem* __restrict__ xpts, const uint8_t* __restrict__ xsc_be,
+                                                 const uint32_t* __restrict__ xoff, int nblk, int nxblk, xyzz* __restrict__ vartab,
+                                                 xyzz* __restrict__ partial) {
+    __shared__ xyzz red[FB_T];
+    const int tid = threadIdx.x, blk = blockIdx.x, job = blockIdx.y;
+    xyzz acc = xyzz_inf();
+    if (blk < nblk) {
+        const uint32_t t0 = toff[job], t1 = toff[job + 1];
+        const size_t items = (size_t)(t1 - t0) * W;
+        for (size_t it = (size_t)blk * FB_T + tid; it < items; it += (size_t)nblk * FB_T) {
+            const uint32_t t = t0 + (uint32_t)(it / W);
+            const int w = (int)(it % W);
+            int d = dig[(size_t)t * W + w];
+            if (d == -32768) d = 32768;  // c = 16: the digit +2^15 wraps in int16; -2^15 itself never occurs
+            if (d != 0) {
+                affine e = affine_load(table[((size_t)gidx[t] * W + w) * NB + ((d < 0 ? -d : d) - 1)]);
+                if (d < 0) e.y = fp_neg(e.y);
+                xyzz_madd(acc, e);
+            }
+        }
+    } else {
+        const uint32_t x0 = xoff[job], x1 = xoff[job + 1];
+        const int xb = blk - nblk;
+        xyzz* tab = vartab + (((size_t)job * nxblk + xb) * FB_T + tid) * ECMUL_NT;
+        for (uint32_t v = x0 + (uint32_t)xb * FB_T + tid; v < x1; v += (uint32_t)nxblk * FB_T) {
+            xyzz r = ec_mul_glv(affine_load(xpts[v]), fq_from_be_reduce(xsc_be + 32 * (size_t)v), tab);
+            xyzz_add(acc, r);
+        }
+    }
+    xyzz s = fb_block_sum(acc, red, tid);
+    if (tid == 0) partial[(size_t)job * (nblk + nxblk) + blk] = s;
+}
+
+__global__ __launch_bounds__(FB_T) void k_fb_final(const xyzz* __restrict__ partial, int nparts, uint8_t* __restrict__ out_be) {
+    __shared__ xyzz red[FB_T];
+    const int tid = threadIdx.x, job = blockIdx.x;
+    xyzz acc = xyzz_inf();
+    for (int i = tid; i < nparts; i += FB_T) {
+        xyzz o = partial[(size_t)job * nparts + i];
+        xyzz_add(acc, o);
+    }
+    xyzz s = fb_block_sum(acc, red, tid);
+    if (tid == 0) affine_to_be64(out_be + 64 * (size_t)job, xyzz_to_affine(s));
+}
+
+size_t fb_vartab_bytes(size_t njobs, int nxblk) { return njobs * (size_t)nxblk * FB_T * ECMUL_NT * sizeof(xyzz); }
+
+// nblk: blocks per job over the generator items (>= 1); nxblk: blocks per job over the extras (0 = none)
+hipError_t launch_fb_msm(size_t njobs, const affine_mem* table, int W, int NB, const int16_t* dig, const uint32_t* gidx, const uint32_t* toff,
+                         const affine_mem* xpts, const uint8_t* xsc_be, const uint32_t* xoff, int nblk, int nxblk, xyzz* vartab, xyzz* partial,
+                         uint8_t* out_be, hipStream_t st) {
+    if (njobs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fb_acc, dim3((unsigned)(nblk + nxblk), (unsigned)njobs), dim3(FB_T), 0, st, table, W, NB, dig, gidx, toff, xpts, xsc_be,
+                       xoff, nblk, nxblk, vartab, partial);
+    hipLaunchKernelGGL(k_fb_final, dim3((unsigned)njobs), dim3(FB_T), 0, st, partial, nblk + nxblk, out_be);
+    return hipGetLastError();
+}
+
+}  // namespace bp

@@ -63,6 +63,12 @@ size_t mb_vartab_bytes(size_t njobs);
 hipError_t launch_mb_msm(size_t njobs, int np, const affine_mem* table, int c, int W, const int16_t* digF, const uint8_t* has_gen,
                          const affine_mem* xpts, const uint8_t* xsc_be, const uint32_t* xoff, xyzz* vartab, xyzz* out, hipStream_t st);
 
+// fbmsm.hip: few jobs over the generator table, whole-chip parallel (prover / single-proof verifier)
+size_t fb_vartab_bytes(size_t njobs, int nxblk);
+hipError_t launch_fb_msm(size_t njobs, const affine_mem* table, int W, int NB, const int16_t* dig, const uint32_t* gidx, const uint32_t* toff,
+                         const affine_mem* xpts, const uint8_t* xsc_be, const uint32_t* xoff, int nblk, int nxblk, xyzz* vartab, xyzz* partial,
+                         uint8_t* out_be, hipStream_t st);
+
 // ecbatch_kernels.hip
 size_t ecbatch_vartab_bytes(size_t n);
 hipError_t launch_scalar_mul_batch(const affine_mem* pts, const uint8_t* scalars_be, size_t n, affine_mem* out, xyzz* vartab, hipStream_t st);

@@ -141,6 +141,116 @@ int dfold(bp_ctx* ctx, const affine_mem* lo, const affine_mem* hi, size_t n_half
     return BP_OK;
 }
 
+// ---- MSM over the resident generator table (fbmsm.hip) -------------------------------------------
+// A job = sparse generator terms (index into g_vec | h_vec | G | H, scalar) + job-specific points.
+// Every job of one call runs concurrently; one upload, one read-back, one synchronisation per call.
+struct FbJob {
+    std::vector<uint32_t> gi;
+    std::vector<Fq> gs;
+    std::vector<Pt> xp;
+    std::vector<Fq> xs;
+    void gen(size_t idx, const Fq& s) {
+        if (s.is_zero()) return;  // the same group element; the reference skips zero terms too (inner_product.rs:74)
+        gi.push_back((uint32_t)idx);
+        gs.push_back(s);
+    }
+    void extra(const Pt& p, const Fq& s) {
+        xp.push_back(p);
+        xs.push_back(s);
+    }
+};
+
+int pin_reserve(bp_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->h_pin_cap) return BP_OK;
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    ctx->h_pin = nullptr;
+    ctx->h_pin_cap = 0;
+    size_t want = bytes + bytes / 2 + 4096;
+    HIPCHK(hipHostMalloc(&ctx->h_pin, want, hipHostMallocDefault), "hipHostMalloc");
+    ctx->h_pin_cap = want;
+    return BP_OK;
+}
+
+int fbmsm(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs, Pt* out) {
+    const size_t nj = jobs.size();
+    if (!nj) return BP_OK;
+    size_t nt = 0, nx = 0, max_t = 0, max_x = 0;
+    for (auto& j : jobs) {
+        nt += j.gi.size();
+        nx += j.xp.size();
+        if (j.gi.size() > max_t) max_t = j.gi.size();
+        if (j.xp.size() > max_x) max_x = j.xp.size();
+    }
+    const size_t nta = nt ? nt : 1, nxa = nx ? nx : 1;
+    const int W = g->W, NB = g->NB;
+    int nblk = (int)((max_t * (size_t)W + 255) / 256);
+    if (nblk < 1) nblk = 1;
+    if (nblk > 128) nblk = 128;
+    const int nxblk = (int)((max_x + 255) / 256);
+    if (nxblk > 64 || nt >= ((size_t)1 << 31) || nx >= ((size_t)1 << 31)) {
+        set_error_msg("internal: fixed-table MSM job too large");
+        return BP_EINVAL;
+    }
+    const int nparts = nblk + nxblk;
+    // upload region: identical layout on the host (pinned) and on the device
+    const size_t o_sc = 0, o_xsc = o_sc + nta * 32, o_xbe = o_xsc + nxa * 32, o_gidx = o_xbe + nxa * 64, o_toff = o_gidx + nta * 4,
+                 o_xoff = o_toff + (nj + 1) * 4, up_bytes = o_xoff + (nj + 1) * 4;
+    const size_t o_xpts = (up_bytes + 63) / 64 * 64;
+    const size_t out_bytes = nj * 64 + sizeof(int);
+    RC(pin_reserve(ctx, up_bytes + out_bytes));
+    RC(ctx->fb[0].reserve(o_xpts + nxa * sizeof(affine_mem)));
+    RC(ctx->fb[1].reserve(nta * (size_t)W * sizeof(int16_t)));
+    RC(ctx->fb[2].reserve(nj * (size_t)nparts * sizeof(xyzz) + out_bytes));
+    if (nxblk) RC(ctx->vartab.reserve(fb_vartab_bytes(nj, nxblk)));
+    uint8_t* hp = (uint8_t*)ctx->h_pin;
+    uint32_t* h_gidx = (uint32_t*)(hp + o_gidx);
+    uint32_t* h_toff = (uint32_t*)(hp + o_toff);
+    uint32_t* h_xoff = (uint32_t*)(hp + o_xoff);
+    size_t t = 0, x = 0;
+    for (size_t j = 0; j < nj; j++) {
+        h_toff[j] = (uint32_t)t;
+        h_xoff[j] = (uint32_t)x;
+        for (size_t i = 0; i < jobs[j].gi.size(); i++, t++) {
+            if (jobs[j].gi[i] >= (uint32_t)g->np) {
+                set_error_msg("internal: generator index out of range");
+                return BP_EINVAL;
+            }
+            h_gidx[t] = jobs[j].gi[i];
+            jobs[j].gs[i].to_be(hp + o_sc + 32 * t);
+        }
+        for (size_t i = 0; i < jobs[j].xp.size(); i++, x++) {
+            memcpy(hp + o_xbe + 64 * x, jobs[j].xp[i].b, 64);
+            jobs[j].xs[i].to_be(hp + o_xsc + 32 * x);
+        }
+    }
+    h_toff[nj] = (uint32_t)t;
+    h_xoff[nj] = (uint32_t)x;
+    hipStream_t st = ctx->stream;
+    uint8_t* d = (uint8_t*)ctx->fb[0].p;
+    affine_mem* d_xpts = (affine_mem*)(d + o_xpts);
+    xyzz* d_partial = (xyzz*)ctx->fb[2].p;
+    uint8_t* d_out = (uint8_t*)(d_partial + nj * (size_t)nparts);
+    int* d_err = (int*)(d_out + nj * 64);
+    HIPCHK(hipMemsetAsync(d_err, 0, sizeof(int), st), "memset");
+    HIPCHK(hipMemcpyAsync(d, hp, up_bytes, hipMemcpyHostToDevice, st), "h2d");
+    if (nx) HIPCHK(launch_ingest_points(d + o_xbe, d_xpts, nx, d_err, st), "ingest");
+    if (nt) HIPCHK(launch_mb_digits(d + o_sc, nt, g->c, W, (int16_t*)ctx->fb[1].p, st), "digits");
+    HIPCHK(launch_fb_msm(nj, g->d_table, W, NB, (const int16_t*)ctx->fb[1].p, (const uint32_t*)(d + o_gidx), (const uint32_t*)(d + o_toff), d_xpts,
+                         d + o_xsc, (const uint32_t*)(d + o_xoff), nblk, nxblk, (xyzz*)ctx->vartab.p, d_partial, d_out, st),
+           "fb_msm");
+    uint8_t* h_out = hp + up_bytes;
+    HIPCHK(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st), "d2h");
+    HIPCHK(hipStreamSynchronize(st), "sync");
+    int h_err;
+    memcpy(&h_err, h_out + nj * 64, sizeof(int));
+    if (h_err) {
+        set_error_msg("input point not on curve");
+        return BP_EPOINT;
+    }
+    for (size_t j = 0; j < nj; j++) memcpy(out[j].b, h_out + 64 * j, 64);
+    return BP_OK;
+}
+
 // ---- shared pieces -------------------------------------------------------------------------------
 struct Gens {
     const bp_gens* g;
@@ -275,6 +385,67 @@ int ipa_prove(bp_ctx* ctx, const affine_mem* G0, const affine_mem* H0, size_t n,
     return BP_OK;
 }
 
+// InnerProductArg::prove (:36-169) without ever folding a base: after j rounds the folded bases are
+//   G^(j)[i] = sum_{t = i mod n'} cG[t] g_t,   H^(j)[i] = sum_{t = i mod n'} cH[t] h_t     (n' = nm / 2^j)
+// with cG/cH products of the challenges (G_new = x^-1 G_L + x G_R, :140-146: indices in the lower half of
+// their n'-block pick up x^-1, the upper half x; H the other way round, :149-155), so every L_j / R_j is an
+// MSM over the ORIGINAL generators with host-computed scalars - table gathers only, no doublings, no
+// base-folding multiplications.  cH enters with the hi_tag factors y^-i (range_proof.rs:223-233),
+// ux = xu * G (:219).  Same group elements, hence the same proof bytes.
+int ipa_prove_fixed(bp_ctx* ctx, const bp_gens* g, std::vector<Fq> cH, const Fq& xu, const Pt& ux, std::vector<Fq> a, std::vector<Fq> b, Ipa& out) {
+    const size_t nm = g->nm, iG = 2 * nm;
+    size_t n = nm;
+    std::vector<Fq> cG(nm, Fq(1));
+    std::vector<FbJob> jobs(2);
+    while (n != 1) {
+        const size_t h = n / 2;
+        Fq cL = inner_product(&a[0], &b[h], h), cR = inner_product(&a[h], &b[0], h);
+        FbJob &jl = jobs[0], &jr = jobs[1];
+        jl = FbJob();
+        jr = FbJob();
+        for (size_t t = 0; t < nm; t++) {
+            const size_t r = t & (n - 1);
+            if (r >= h) {
+                jl.gen(t, a[r - h] * cG[t]);       // <a_L, G_R>   (:70-90)
+                jr.gen(nm + t, b[r - h] * cH[t]);  // <b_L, H_R>   (:95-115)
+            } else {
+                jl.gen(nm + t, b[h + r] * cH[t]);  // <b_R, H_L>
+                jr.gen(t, a[h + r] * cG[t]);       // <a_R, G_L>
+            }
+        }
+        jl.gen(iG, cL * xu);
+        jr.gen(iG, cR * xu);
+        Pt LR[2];
+        RC(fbmsm(ctx, g, jobs, LR));
+        if (LR[0].is_inf() || LR[1].is_inf()) {
+            set_error_msg("L or R is the identity (cannot be hashed)");
+            return BP_EINVAL;
+        }
+        Fq x = Transcript().point(LR[0].b).point(LR[1].b).point(ux.b).result_scalar();  // :117
+        if (x.is_zero()) return BP_EINVAL;
+        Fq xi = x.inv();
+        std::vector<Fq> an(h), bn(h);
+        for (size_t i = 0; i < h; i++) {
+            an[i] = a[i] * x + a[h + i] * xi;  // :122-128
+            bn[i] = b[h + i] * x + b[i] * xi;  // :131-137
+        }
+        if (h != 1)
+            for (size_t t = 0; t < nm; t++) {
+                const bool lower = (t & (n - 1)) < h;
+                cG[t] = cG[t] * (lower ? xi : x);
+                cH[t] = cH[t] * (lower ? x : xi);
+            }
+        a.swap(an);
+        b.swap(bn);
+        out.L.push_back(LR[0]);
+        out.R.push_back(LR[1]);
+        n = h;
+    }
+    out.a = a[0];
+    out.b = b[0];
+    return BP_OK;
+}
+
 // challenges x_j of an IPA proof and the s vector (inner_product.rs:276-306)
 int ipa_challenges(const Ipa& p, const Pt& ux, std::vector<Fq>& x, std::vector<Fq>& xinv) {
     for (size_t j = 0; j < p.L.size(); j++) {
@@ -297,34 +468,6 @@ std::vector<Fq> s_vector(const std::vector<Fq>& x, const std::vector<Fq>& xinv, 
         s[i] = s[i - ((size_t)1 << lg)] * x[(k - 1) - lg] * x[(k - 1) - lg];
     }
     return s;
-}
-
-// fast_verify (:253-345): one MSM of 2n + 2k + 1 terms
-int ipa_fast_verify(bp_ctx* ctx, const Ipa& p, const affine_mem* G, const affine_mem* H, size_t n, const Pt& ux, const Pt& P, bool& ok) {
-    std::vector<Fq> x, xinv;
-    if (ipa_challenges(p, ux, x, xinv) != BP_OK) {
-        ok = false;
-        return BP_OK;
-    }
-    std::vector<Fq> s = s_vector(x, xinv, n);
-    std::vector<Fq> sc;
-    for (size_t i = 0; i < n; i++) sc.push_back(s[i] * p.a);
-    for (size_t i = 0; i < n; i++) sc.push_back(s[i].inv() * p.b);  // :312-317
-    std::vector<Pt> ex;
-    for (size_t j = 0; j < x.size(); j++) {
-        sc.push_back(-(x[j] * x[j]));
-        ex.push_back(p.L[j]);
-    }
-    for (size_t j = 0; j < x.size(); j++) {
-        sc.push_back(-(xinv[j] * xinv[j]));
-        ex.push_back(p.R[j]);
-    }
-    sc.push_back(p.a * p.b);
-    ex.push_back(ux);
-    Pt got;
-    RC(dmsm(ctx, {Part(G, n), Part(H, n)}, ex, sc, got));
-    ok = got == P;
-    return BP_OK;
 }
 
 // verify (:171-244): folds the bases every round
@@ -520,15 +663,16 @@ int bp_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint
         aL[i] = Fq(bits[i]);
         aR[i] = aL[i] - ONE;  // :81-83
     }
+    const size_t iG = 2 * nm, iH = 2 * nm + 1;  // generator indices of G and H in the table
+    std::vector<FbJob> jobs(2);
     // A = alpha H + sum_{bit} g_i - sum_{!bit} h_i   (:63, 93-107)
-    std::vector<Fq> sc(2 * nm + 1);
     for (size_t i = 0; i < nm; i++) {
-        sc[i] = bits[i] ? ONE : ZERO;
-        sc[nm + i] = bits[i] ? ZERO : -ONE;
+        if (bits[i])
+            jobs[0].gen(i, ONE);
+        else
+            jobs[0].gen(nm + i, -ONE);
     }
-    sc[2 * nm] = alpha;
-    Pt A, S;
-    RC(dmsm(ctx, {Part(gn.gv, nm), Part(gn.hv, nm), Part(gn.H, 1)}, {}, sc, A));
+    jobs[0].gen(iH, alpha);
     std::vector<Fq> SR(nm), SL(nm);
     for (size_t i = 0; i < nm; i++) SR[i] = tp.next();  // :109-111 (SR first)
     for (size_t i = 0; i < nm; i++) SL[i] = tp.next();  // :112-114
@@ -537,17 +681,21 @@ int bp_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint
         set_error_msg("randomness tape: need 2nm+4 scalars in [1, q)");
         return BP_EINVAL;
     }
-    // S = rho H + sum SL_i g_i + SR_i h_i   (:64, 116-122)
+    // S = rho H + sum SL_i g_i + SR_i h_i   (:64, 116-122); A and S in one launch
     for (size_t i = 0; i < nm; i++) {
-        sc[i] = SL[i];
-        sc[nm + i] = SR[i];
+        jobs[1].gen(i, SL[i]);
+        jobs[1].gen(nm + i, SR[i]);
     }
-    sc[2 * nm] = rho;
-    RC(dmsm(ctx, {Part(gn.gv, nm), Part(gn.hv, nm), Part(gn.H, 1)}, {}, sc, S));
+    jobs[1].gen(iH, rho);
+    Pt AS[2];
+    RC(fbmsm(ctx, gens, jobs, AS));
+    const Pt &A = AS[0], &S = AS[1];
     if (A.is_inf() || S.is_inf()) return BP_EINVAL;
     Fq y = Transcript().point(A.b).point(S.b).result_scalar();  // :124
     Pt yG;
-    RC(dmsm(ctx, {Part(gn.G, 1)}, {}, {y}, yG));  // :126
+    jobs.assign(1, FbJob());
+    jobs[0].gen(iG, y);
+    RC(fbmsm(ctx, gens, jobs, &yG));  // :126
     if (yG.is_inf()) return BP_EINVAL;
     Fq z = Transcript().point(yG.b).result_scalar();  // :127
     std::vector<Fq> yi(nm), vec_2n(n), zpow(m + 2);
@@ -562,9 +710,14 @@ int bp_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint
         Fq zj2k = zpow[i / n] * vec_2n[i % n];
         t1 = t1 + SL[i] * ((aR[i] + z) * yi[i]) + (aL[i] - z) * (SR[i] * yi[i]) + zj2k * SL[i];  // :145-162
     }
-    Pt T1, T2;
-    RC(dmsm(ctx, {Part(gn.G, 1), Part(gn.H, 1)}, {}, {t1, tau1}, T1));  // :168
-    RC(dmsm(ctx, {Part(gn.G, 1), Part(gn.H, 1)}, {}, {t2, tau2}, T2));  // :169
+    Pt T12[2];
+    jobs.assign(2, FbJob());
+    jobs[0].gen(iG, t1);  // T1 = t1 G + tau1 H   (:168)
+    jobs[0].gen(iH, tau1);
+    jobs[1].gen(iG, t2);  // T2 = t2 G + tau2 H   (:169)
+    jobs[1].gen(iH, tau2);
+    RC(fbmsm(ctx, gens, jobs, T12));
+    const Pt &T1 = T12[0], &T2 = T12[1];
     if (T1.is_inf() || T2.is_inf()) return BP_EINVAL;
     Fq x = Transcript().point(T1.b).point(T2.b).point(gn.Gh.b).point(gn.Hh.b).result_scalar();  // :171
     Fq tau_x = x * tau1 + x * x * tau2;
@@ -579,7 +732,9 @@ int bp_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint
     }
     Fq xu = Transcript().scalar(tau_x).scalar(miu).scalar(tx).result_scalar();  // :214-218
     Pt Gx;
-    RC(dmsm(ctx, {Part(gn.G, 1)}, {}, {xu}, Gx));  // :219
+    jobs.assign(1, FbJob());
+    jobs[0].gen(iG, xu);
+    RC(fbmsm(ctx, gens, jobs, &Gx));  // :219
     if (Gx.is_inf()) return BP_EINVAL;
     // hi_tag = y^-i h_i   (:223-233)
     std::vector<Fq> yinv(nm);
@@ -587,11 +742,15 @@ int bp_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint
     if (y.is_zero()) return BP_EINVAL;
     yinv[0] = ONE;
     for (size_t i = 1; i < nm; i++) yinv[i] = yinv[i - 1] * yi1;
-    RC(ctx->proto[4].reserve(nm * sizeof(affine_mem)));
-    affine_mem* hi_tag = (affine_mem*)ctx->proto[4].p;
-    RC(dscalar_mul_batch(ctx, gn.hv, yinv, hi_tag));
     Ipa ipa;
-    RC(ipa_prove(ctx, gn.gv, hi_tag, nm, Gx, Lp, Rp, ipa));  // :250-251
+    if (ctx->proto_path == 1) {  // reference-structured rounds: materialised hi_tag, bases folded every round
+        RC(ctx->proto[4].reserve(nm * sizeof(affine_mem)));
+        affine_mem* hi_tag = (affine_mem*)ctx->proto[4].p;
+        RC(dscalar_mul_batch(ctx, gn.hv, yinv, hi_tag));
+        RC(ipa_prove(ctx, gn.gv, hi_tag, nm, Gx, Lp, Rp, ipa));  // :250-251
+    } else {
+        RC(ipa_prove_fixed(ctx, gens, yinv, xu, Gx, Lp, Rp, ipa));
+    }
     // canonical encoding
     uint8_t* q = proof_out;
     const Pt* pp[4] = {&A, &S, &T1, &T2};
@@ -636,22 +795,21 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
         }
     }
     const Fq ONE(1), ZERO;
+    const size_t iG = 2 * nm, iH = 2 * nm + 1;
     Fq y = Transcript().point(pf.A.b).point(pf.S.b).result_scalar();
-    Pt yG;
-    RC(dmsm(ctx, {Part(gn.G, 1)}, {}, {y}, yG));
-    if (y.is_zero() || yG.is_inf()) {
+    Fq xu = Transcript().bigint32(pf.tau_x_be).bigint32(pf.miu_be).bigint32(pf.tx_be).result_scalar();
+    std::vector<FbJob> jobs(2);
+    jobs[0].gen(iG, y);   // base_point * y   (:588)
+    jobs[1].gen(iG, xu);  // ux = G * x_u     (:657-658)
+    Pt yGux[2];
+    RC(fbmsm(ctx, gens, jobs, yGux));
+    const Pt &yG = yGux[0], &ux = yGux[1];
+    if (y.is_zero() || yG.is_inf() || ux.is_inf()) {
         *verdict = BP_VERDICT_MALFORMED;
         return BP_OK;
     }
     Fq z = Transcript().point(yG.b).result_scalar();
     Fq x = Transcript().point(pf.T1.b).point(pf.T2.b).point(gn.Gh.b).point(gn.Hh.b).result_scalar();
-    Fq xu = Transcript().bigint32(pf.tau_x_be).bigint32(pf.miu_be).bigint32(pf.tx_be).result_scalar();
-    Pt ux;
-    RC(dmsm(ctx, {Part(gn.G, 1)}, {}, {xu}, ux));
-    if (ux.is_inf()) {
-        *verdict = BP_VERDICT_MALFORMED;
-        return BP_OK;
-    }
     std::vector<Fq> yi(nm), yinv(nm), vec_2n(n), zpow(m + 2);
     Fq yi1 = y.inv();
     yi[0] = yinv[0] = ONE;
@@ -667,7 +825,7 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
     for (size_t i = 0; i < n; i++) sum_2n = sum_2n + vec_2n[i];
 
     if (mode == 2) {
-        // aggregated_verify (:537-782)
+        // aggregated_verify (:537-782): one MSM - generator terms from the table, proof points by GLV ladders
         Fq cver = Transcript().point(pf.A.b).point(pf.S.b).point(pf.T1.b).point(pf.T2.b).point(gn.Gh.b).point(gn.Hh.b).result_scalar();
         std::vector<Fq> xs, xinv;
         if (ipa_challenges(pf.ipa, ux, xs, xinv) != BP_OK) {
@@ -676,81 +834,76 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
         }
         std::vector<Fq> s = s_vector(xs, xinv, nm);
         Fq sum_d;
-        std::vector<Fq> sc(2 * nm + 1);
+        jobs.assign(1, FbJob());
+        FbJob& jb = jobs[0];
         for (size_t i = 0; i < nm; i++) {
             Fq d = vec_2n[i % n] * zpow[i / n];
             sum_d = sum_d + d;
-            sc[i] = s[i] * pf.ipa.a + z;                                   // :694-696
-            sc[nm + i] = yinv[i] * (s[nm - 1 - i] * pf.ipa.b - d) - z;     // :699-705 (s_i^-1 = s_{nm-1-i})
+            jb.gen(i, s[i] * pf.ipa.a + z);                                  // :694-696
+            jb.gen(nm + i, yinv[i] * (s[nm - 1 - i] * pf.ipa.b - d) - z);    // :699-705 (s_i^-1 = s_{nm-1-i})
         }
-        Fq delta = (z - z * z) * sum_y - sum_d * z;  // :639-642
-        sc[2 * nm] = xu * (pf.ipa.a * pf.ipa.b - pf.tx) + cver * (delta - pf.tx);  // G  :708-719
-        std::vector<Pt> ex;
-        ex.push_back(gn.Hh);
-        sc.push_back(pf.miu - cver * pf.tau_x);  // H  :722-723, 770
-        ex.push_back(pf.S);
-        sc.push_back(-x);
-        for (int j = 0; j < k; j++) {
-            ex.push_back(pf.ipa.L[j]);
-            sc.push_back(-(xs[j] * xs[j]));
-        }
-        for (int j = 0; j < k; j++) {
-            ex.push_back(pf.ipa.R[j]);
-            sc.push_back(-(xinv[j] * xinv[j]));
-        }
-        for (int j = 0; j < m; j++) {
-            ex.push_back(V[j]);
-            sc.push_back(cver * zpow[j]);
-        }
-        ex.push_back(pf.T1);
-        sc.push_back(cver * x);
-        ex.push_back(pf.T2);
-        sc.push_back(cver * x * x);
+        Fq delta = (z - z * z) * sum_y - sum_d * z;                                      // :639-642
+        jb.gen(iG, xu * (pf.ipa.a * pf.ipa.b - pf.tx) + cver * (delta - pf.tx));         // G  :708-719
+        jb.gen(iH, pf.miu - cver * pf.tau_x);                                            // H  :722-723, 770
+        jb.extra(pf.S, -x);
+        for (int j = 0; j < k; j++) jb.extra(pf.ipa.L[j], -(xs[j] * xs[j]));
+        for (int j = 0; j < k; j++) jb.extra(pf.ipa.R[j], -(xinv[j] * xinv[j]));
+        for (int j = 0; j < m; j++) jb.extra(V[j], cver * zpow[j]);
+        jb.extra(pf.T1, cver * x);
+        jb.extra(pf.T2, cver * x * x);
         Pt lhs;
-        RC(dmsm(ctx, {Part(gn.gv, nm), Part(gn.hv, nm), Part(gn.G, 1)}, ex, sc, lhs));
+        RC(fbmsm(ctx, gens, jobs, &lhs));
         *verdict = (lhs == pf.A) ? BP_VERDICT_OK : BP_VERDICT_RANGE_PROOF_ERROR;  // :777
         return BP_OK;
     }
 
-    // verify / fast_verify common part (:274-391 / :409-526)
+    // verify / fast_verify common part (:274-391 / :409-526); hi_tag_i = y^-i h_i enters through its scalar
     Fq zc2n;
     for (int j = 0; j < m; j++) zc2n = zc2n + z.pow(3 + (uint64_t)j) * sum_2n;  // :311-317
     Fq delta = (z - z * z) * sum_y - zc2n;                                      // :319-321
-    RC(ctx->proto[4].reserve(nm * sizeof(affine_mem)));
-    affine_mem* hi_tag = (affine_mem*)ctx->proto[4].p;
-    RC(dscalar_mul_batch(ctx, gn.hv, yinv, hi_tag));  // :323-329
-    Pt left, right;
-    RC(dmsm(ctx, {Part(gn.G, 1), Part(gn.H, 1)}, {}, {pf.tx, pf.tau_x}, left));  // eq 65  :337-339
-    {
-        std::vector<Pt> ex(V.begin(), V.end());
-        std::vector<Fq> sc;
-        for (int j = 0; j < m; j++) sc.push_back(zpow[j]);
-        ex.push_back(gn.Gh);
-        sc.push_back(delta);
-        ex.push_back(pf.T1);
-        sc.push_back(x);
-        ex.push_back(pf.T2);
-        sc.push_back(x * x);
-        RC(dmsm(ctx, {}, ex, sc, right));  // :340-354
-    }
+    jobs.assign(mode == 1 ? 4 : 3, FbJob());
+    jobs[0].gen(iG, pf.tx);  // eq 65, left   (:337-339)
+    jobs[0].gen(iH, pf.tau_x);
+    for (int j = 0; j < m; j++) jobs[1].extra(V[j], zpow[j]);  // eq 65, right  (:340-354)
+    jobs[1].gen(iG, delta);
+    jobs[1].extra(pf.T1, x);
+    jobs[1].extra(pf.T2, x * x);
     // P = -miu H + tx Gx + A + x S + sum (z y^i + z^(2+j) 2^k) hi_tag_i - z sum g_i   (:361-391)
-    Pt P;
-    {
-        std::vector<Fq> sc;
-        for (size_t i = 0; i < nm; i++) sc.push_back(z * yi[i] + zpow[i / n] * vec_2n[i % n]);
-        for (size_t i = 0; i < nm; i++) sc.push_back(-z);
-        std::vector<Pt> ex = {gn.Hh, ux, pf.A, pf.S};
-        sc.push_back(-pf.miu);
-        sc.push_back(pf.tx);
-        sc.push_back(ONE);
-        sc.push_back(x);
-        RC(dmsm(ctx, {Part(hi_tag, nm), Part(gn.gv, nm)}, ex, sc, P));
+    for (size_t i = 0; i < nm; i++) {
+        jobs[2].gen(nm + i, (z * yi[i] + zpow[i / n] * vec_2n[i % n]) * yinv[i]);
+        jobs[2].gen(i, -z);
     }
-    bool ok = false;
-    if (mode == 1)
-        RC(ipa_fast_verify(ctx, pf.ipa, gn.gv, hi_tag, nm, ux, P, ok));
-    else
+    jobs[2].gen(iH, -pf.miu);
+    jobs[2].gen(iG, pf.tx * xu);
+    jobs[2].extra(pf.A, ONE);
+    jobs[2].extra(pf.S, x);
+    bool ok = false, chal_ok = true;
+    if (mode == 1) {
+        // InnerProductArg::fast_verify (inner_product.rs:253-345): one MSM of 2nm + 2k + 1 terms
+        std::vector<Fq> xs, xinv;
+        chal_ok = ipa_challenges(pf.ipa, ux, xs, xinv) == BP_OK;
+        if (chal_ok) {
+            std::vector<Fq> s = s_vector(xs, xinv, nm);
+            for (size_t i = 0; i < nm; i++) {
+                jobs[3].gen(i, s[i] * pf.ipa.a);
+                jobs[3].gen(nm + i, s[nm - 1 - i] * pf.ipa.b * yinv[i]);  // :312-317 (s_i^-1 = s_{nm-1-i})
+            }
+            for (int j = 0; j < k; j++) jobs[3].extra(pf.ipa.L[j], -(xs[j] * xs[j]));
+            for (int j = 0; j < k; j++) jobs[3].extra(pf.ipa.R[j], -(xinv[j] * xinv[j]));
+            jobs[3].gen(iG, pf.ipa.a * pf.ipa.b * xu);
+        }
+    }
+    Pt res[4];
+    RC(fbmsm(ctx, gens, jobs, res));
+    const Pt &left = res[0], &right = res[1], &P = res[2];
+    if (mode == 1) {
+        ok = chal_ok && res[3] == P;
+    } else {
+        RC(ctx->proto[4].reserve(nm * sizeof(affine_mem)));
+        affine_mem* hi_tag = (affine_mem*)ctx->proto[4].p;
+        RC(dscalar_mul_batch(ctx, gn.hv, yinv, hi_tag));  // :323-329
         RC(ipa_verify(ctx, pf.ipa, gn.gv, hi_tag, nm, ux, P, ok));
+    }
     *verdict = (ok && left == right) ? BP_VERDICT_OK : BP_VERDICT_RANGE_PROOF_ERROR;  // :393-397
     return BP_OK;
 }
@@ -860,6 +1013,91 @@ int wip_prove(bp_ctx* ctx, const affine_mem* G0, const affine_mem* H0, size_t n,
     return BP_OK;
 }
 
+// WeightedInnerProdArg::prove (:47-268) over the UNFOLDED generators (see ipa_prove_fixed):
+// G_hat = x^-1 G_L + (x y^-n') G_R (:187-195), H_hat = x H_L + x^-1 H_R (:198-204), g = G, h = H.
+int wip_prove_fixed(bp_ctx* ctx, const bp_gens* g, const Pt& gh, const Pt& hh, std::vector<Fq> a, std::vector<Fq> b, Fq alpha, const Fq& y, Tape& tp,
+                    WipArg& out) {
+    const size_t nm = g->nm, iG = 2 * nm, iH = 2 * nm + 1;
+    size_t n = nm;
+    if (y.is_zero()) return BP_EINVAL;
+    Fq yinv = y.inv();
+    std::vector<Fq> cG(nm, Fq(1)), cH(nm, Fq(1));
+    std::vector<FbJob> jobs(2);
+    while (n != 1) {
+        const size_t h = n / 2;
+        Fq yn = y.pow(h), yninv = yinv.pow(h);  // powers_y[n-1], powers_yinv[n-1]  (:71-76, :91, :94)
+        std::vector<Fq> yn_aR(h), yninv_aL(h);
+        for (size_t i = 0; i < h; i++) {
+            yn_aR[i] = yn * a[h + i];
+            yninv_aL[i] = yninv * a[i];
+        }
+        Fq cL = weighted_inner_product(&a[0], &b[h], h, y), cR = weighted_inner_product(&yn_aR[0], &b[0], h, y);
+        Fq dL = tp.next();  // :106
+        Fq dR = tp.next();  // :134
+        if (!tp.ok) return BP_EINVAL;
+        FbJob &jl = jobs[0], &jr = jobs[1];
+        jl = FbJob();
+        jr = FbJob();
+        for (size_t t = 0; t < nm; t++) {
+            const size_t r = t & (n - 1);
+            if (r >= h) {
+                jl.gen(t, yninv_aL[r - h] * cG[t]);  // <y^-n' a_L, G_R>   (:103-126)
+                jr.gen(nm + t, b[r - h] * cH[t]);    // <b_L, H_R>         (:131-154)
+            } else {
+                jl.gen(nm + t, b[h + r] * cH[t]);  // <b_R, H_L>
+                jr.gen(t, yn_aR[r] * cG[t]);       // <y^n' a_R, G_L>
+            }
+        }
+        jl.gen(iG, cL);
+        jl.gen(iH, dL);
+        jr.gen(iG, cR);
+        jr.gen(iH, dR);
+        Pt LR[2];
+        RC(fbmsm(ctx, g, jobs, LR));
+        if (LR[0].is_inf() || LR[1].is_inf()) return BP_EINVAL;
+        Fq x = Transcript().point(LR[0].b).point(LR[1].b).point(gh.b).point(hh.b).result_scalar();  // :158
+        if (x.is_zero()) return BP_EINVAL;
+        Fq xi = x.inv(), xsq = x * x, xyn = x * yninv;
+        std::vector<Fq> an(h), bn(h);
+        for (size_t i = 0; i < h; i++) {
+            an[i] = a[i] * x + yn_aR[i] * xi;  // :164-170
+            bn[i] = b[h + i] * x + b[i] * xi;  // :173-179
+        }
+        alpha = alpha + xsq * dL + xsq.inv() * dR;  // :182-185
+        for (size_t t = 0; t < nm; t++) {
+            const bool lower = (t & (n - 1)) < h;
+            cG[t] = cG[t] * (lower ? xi : xyn);
+            cH[t] = cH[t] * (lower ? x : xi);
+        }
+        a.swap(an);
+        b.swap(bn);
+        out.L.push_back(LR[0]);
+        out.R.push_back(LR[1]);
+        n = h;
+    }
+    Fq r = tp.next(), s = tp.next(), delta = tp.next(), eta = tp.next();  // :213-219
+    if (!tp.ok) return BP_EINVAL;
+    jobs.assign(2, FbJob());
+    for (size_t t = 0; t < nm; t++) {  // A = r G_1 + s H_1 + (r y b + s y a) g + delta h   (:222-232)
+        jobs[0].gen(t, r * cG[t]);
+        jobs[0].gen(nm + t, s * cH[t]);
+    }
+    jobs[0].gen(iG, a[0] * s * y + b[0] * r * y);
+    jobs[0].gen(iH, delta);
+    jobs[1].gen(iG, y * (r * s));  // B = r y s g + eta h   (:235-239)
+    jobs[1].gen(iH, eta);
+    Pt AB[2];
+    RC(fbmsm(ctx, g, jobs, AB));
+    out.a_tag = AB[0];
+    out.b_tag = AB[1];
+    if (out.a_tag.is_inf() || out.b_tag.is_inf()) return BP_EINVAL;
+    Fq e = Transcript().point(out.a_tag.b).point(out.b_tag.b).point(gh.b).point(hh.b).result_scalar();  // :243
+    out.r_prime = r + a[0] * e;
+    out.s_prime = s + b[0] * e;
+    out.delta_prime = eta + (delta * e + alpha * (e * e));  // :253-256
+    return BP_OK;
+}
+
 // scalars shared by WIP fast_verify (:416-468) and RangeProofWIP::aggregated_verify (:463-516)
 struct WipChal {
     Fq e;
@@ -914,18 +1152,23 @@ int bp_wip_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const 
     std::vector<int> bits = secret_bits(secrets_be, m, n);
     Fq alpha = tp.next();  // :150
     if (!tp.ok) return BP_EINVAL;
-    std::vector<Fq> sc(2 * nm + 1);
+    const size_t iG = 2 * nm, iH = 2 * nm + 1;
+    std::vector<FbJob> jobs(1);
     for (size_t i = 0; i < nm; i++) {
-        sc[i] = bits[i] ? ONE : ZERO;
-        sc[nm + i] = bits[i] ? ZERO : -ONE;
+        if (bits[i])
+            jobs[0].gen(i, ONE);
+        else
+            jobs[0].gen(nm + i, -ONE);
     }
-    sc[2 * nm] = alpha;
+    jobs[0].gen(iH, alpha);
     Pt A;
-    RC(dmsm(ctx, {Part(gn.gv, nm), Part(gn.hv, nm), Part(gn.H, 1)}, {}, sc, A));  // :151-165
+    RC(fbmsm(ctx, gens, jobs, &A));  // :151-165
     if (A.is_inf()) return BP_EINVAL;
     Fq y = Transcript().point(A.b).result_scalar();  // :167
     Pt yG;
-    RC(dmsm(ctx, {Part(gn.G, 1)}, {}, {y}, yG));
+    jobs.assign(1, FbJob());
+    jobs[0].gen(iG, y);
+    RC(fbmsm(ctx, gens, jobs, &yG));
     if (yG.is_inf()) return BP_EINVAL;
     Fq z = Transcript().point(A.b).point(yG.b).result_scalar();  // :171
     PlusScalars ps = plus_common(n, m, y, z);
@@ -940,7 +1183,10 @@ int bp_wip_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const 
     Fq alpha_hat = alpha + scalar_H;  // :262
     BpPlusProof pf;
     pf.A = A;
-    RC(wip_prove(ctx, gn.gv, gn.hv, nm, gn.G, gn.H, gn.Gh, gn.Hh, aL_hat, aR_hat, alpha_hat, y, tp, pf.w));
+    if (ctx->proto_path == 1)
+        RC(wip_prove(ctx, gn.gv, gn.hv, nm, gn.G, gn.H, gn.Gh, gn.Hh, aL_hat, aR_hat, alpha_hat, y, tp, pf.w));
+    else
+        RC(wip_prove_fixed(ctx, gens, gn.Gh, gn.Hh, aL_hat, aR_hat, alpha_hat, y, tp, pf.w));
     uint8_t* q = proof_out;
     host_compress(A.b, q);
     q += 33;
@@ -982,9 +1228,12 @@ int bp_wip_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
             return BP_OK;
         }
     }
+    const size_t iG = 2 * nm, iH = 2 * nm + 1;
     Fq y = Transcript().point(pf.A.b).result_scalar();
     Pt yG;
-    RC(dmsm(ctx, {Part(gn.G, 1)}, {}, {y}, yG));
+    std::vector<FbJob> jobs(1);
+    jobs[0].gen(iG, y);
+    RC(fbmsm(ctx, gens, jobs, &yG));
     if (y.is_zero() || yG.is_inf()) {
         *verdict = BP_VERDICT_MALFORMED;
         return BP_OK;
@@ -999,77 +1248,51 @@ int bp_wip_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
     const Fq e = c.e, esq = c.e * c.e;
     if (mode == 2) {
         // aggregated_verify (:388-609)
-        std::vector<Fq> sc(2 * nm + 1);
+        jobs.assign(1, FbJob());
+        FbJob& jb = jobs[0];
         Fq er = pf.w.r_prime * e, es = pf.w.s_prime * e, esz = z * esq;
         for (size_t i = 0; i < nm; i++) {
-            sc[i] = er * c.sg[i] + esz;                                              // :540-545
-            sc[nm + i] = (es * c.sh[i] - esz) - ps.d[i] * ps.y_pow[nm - 1 - i] * esq;  // :549-557
+            jb.gen(i, er * c.sg[i] + esz);                                                  // :540-545
+            jb.gen(nm + i, (es * c.sh[i] - esz) - ps.d[i] * ps.y_pow[nm - 1 - i] * esq);    // :549-557
         }
-        sc[2 * nm] = pf.w.r_prime * pf.w.s_prime * y - ps.zeta * esq;  // g  :532-535
-        std::vector<Pt> ex;
-        ex.push_back(gn.Hh);
-        sc.push_back(pf.w.delta_prime);  // h * delta'  :598
-        for (int j = 0; j < k; j++) {
-            ex.push_back(pf.w.L[j]);
-            sc.push_back(-(esq * c.x[j] * c.x[j]));
-        }
-        for (int j = 0; j < k; j++) {
-            ex.push_back(pf.w.R[j]);
-            sc.push_back(-(esq * c.xinv[j] * c.xinv[j]));
-        }
-        ex.push_back(pf.A);
-        sc.push_back(-esq);  // P  :564-565
+        jb.gen(iG, pf.w.r_prime * pf.w.s_prime * y - ps.zeta * esq);  // g  :532-535
+        jb.gen(iH, pf.w.delta_prime);                                 // h * delta'  :598
+        for (int j = 0; j < k; j++) jb.extra(pf.w.L[j], -(esq * c.x[j] * c.x[j]));
+        for (int j = 0; j < k; j++) jb.extra(pf.w.R[j], -(esq * c.xinv[j] * c.xinv[j]));
+        jb.extra(pf.A, -esq);  // P  :564-565
         Fq mey = (-esq) * ps.y_nm1;
-        for (int j = 0; j < m; j++) {
-            ex.push_back(V[j]);
-            sc.push_back(ps.z2m[j] * mey);  // :568-571
-        }
-        ex.push_back(pf.w.a_tag);
-        sc.push_back(-e);  // :574
+        for (int j = 0; j < m; j++) jb.extra(V[j], ps.z2m[j] * mey);  // :568-571
+        jb.extra(pf.w.a_tag, -e);                                     // :574
         Pt lhs;
-        RC(dmsm(ctx, {Part(gn.gv, nm), Part(gn.hv, nm), Part(gn.G, 1)}, ex, sc, lhs));
+        RC(fbmsm(ctx, gens, jobs, &lhs));
         *verdict = (lhs == pf.w.b_tag) ? BP_VERDICT_OK : BP_VERDICT_RANGE_PROOF_ERROR;  // :604
         return BP_OK;
     }
     // verify (:276-382): A_hat, then WeightedInnerProdArg::fast_verify (weighted_inner_product.rs:386-515)
-    Pt A_hat;
-    {
-        std::vector<Fq> sc(2 * nm + 1);
-        for (size_t i = 0; i < nm; i++) {
-            sc[i] = -z;
-            sc[nm + i] = ps.d[i] * ps.y_pow[nm - 1 - i] + z;
-        }
-        sc[2 * nm] = ps.zeta;
-        std::vector<Pt> ex(V.begin(), V.end());
-        for (int j = 0; j < m; j++) sc.push_back(ps.y_nm1 * ps.z2m[j]);
-        ex.push_back(pf.A);
-        sc.push_back(Fq(1));
-        RC(dmsm(ctx, {Part(gn.gv, nm), Part(gn.hv, nm), Part(gn.G, 1)}, ex, sc, A_hat));  // :352-372
+    jobs.assign(2, FbJob());
+    for (size_t i = 0; i < nm; i++) {  // A_hat  (:352-372)
+        jobs[0].gen(i, -z);
+        jobs[0].gen(nm + i, ps.d[i] * ps.y_pow[nm - 1 - i] + z);
     }
-    Pt lhs, rhs;
-    {
-        std::vector<Fq> sc(2 * nm);
-        for (size_t i = 0; i < nm; i++) {
-            sc[i] = pf.w.r_prime * (e * c.sg[i]);       // :471-476
-            sc[nm + i] = pf.w.s_prime * (e * c.sh[i]);  // :477-482
-        }
-        std::vector<Pt> ex;
-        for (int j = 0; j < k; j++) {
-            ex.push_back(pf.w.L[j]);
-            sc.push_back(-(esq * c.x[j] * c.x[j]));
-        }
-        for (int j = 0; j < k; j++) {
-            ex.push_back(pf.w.R[j]);
-            sc.push_back(-(esq * c.xinv[j] * c.xinv[j]));
-        }
-        ex.push_back(gn.Gh);
-        sc.push_back(pf.w.r_prime * pf.w.s_prime * y);
-        ex.push_back(gn.Hh);
-        sc.push_back(pf.w.delta_prime);
-        RC(dmsm(ctx, {Part(gn.gv, nm), Part(gn.hv, nm)}, ex, sc, lhs));                         // :500-504
-        RC(dmsm(ctx, {}, {A_hat, pf.w.a_tag, pf.w.b_tag}, {esq, e, Fq(1)}, rhs));               // :506-508
+    jobs[0].gen(iG, ps.zeta);
+    for (int j = 0; j < m; j++) jobs[0].extra(V[j], ps.y_nm1 * ps.z2m[j]);
+    jobs[0].extra(pf.A, Fq(1));
+    for (size_t i = 0; i < nm; i++) {  // left side of the WIP check  (:471-504)
+        jobs[1].gen(i, pf.w.r_prime * (e * c.sg[i]));
+        jobs[1].gen(nm + i, pf.w.s_prime * (e * c.sh[i]));
     }
-    *verdict = (lhs == rhs) ? BP_VERDICT_OK : BP_VERDICT_RANGE_PROOF_ERROR;
+    for (int j = 0; j < k; j++) jobs[1].extra(pf.w.L[j], -(esq * c.x[j] * c.x[j]));
+    for (int j = 0; j < k; j++) jobs[1].extra(pf.w.R[j], -(esq * c.xinv[j] * c.xinv[j]));
+    jobs[1].gen(iG, pf.w.r_prime * pf.w.s_prime * y);
+    jobs[1].gen(iH, pf.w.delta_prime);
+    Pt r1[2], rhs;
+    RC(fbmsm(ctx, gens, jobs, r1));
+    jobs.assign(1, FbJob());
+    jobs[0].extra(r1[0], esq);  // e^2 A_hat + e A + B   (:506-508)
+    jobs[0].extra(pf.w.a_tag, e);
+    jobs[0].extra(pf.w.b_tag, Fq(1));
+    RC(fbmsm(ctx, gens, jobs, &rhs));
+    *verdict = (r1[1] == rhs) ? BP_VERDICT_OK : BP_VERDICT_RANGE_PROOF_ERROR;
     return BP_OK;
 }
 

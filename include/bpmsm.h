@@ -86,6 +86,14 @@ void bp_msm_set_window(bp_ctx* ctx, int c);
  * path (large n).  Both compute the same sum; results are identical. */
 void bp_msm_set_path(bp_ctx* ctx, int path);
 
+/* Testing / tuning knob for the protocol entry points (bp_rangeproof_prove / _verify, bp_wip_*):
+ *   0 (default): every MSM over g_vec / h_vec / G / H is evaluated from the resident fixed-base table; the
+ *      inner-product rounds never fold a base (L_j / R_j are MSMs over the original generators with
+ *      host-computed coefficients) — same group elements, same proof bytes, same verdicts;
+ *   1: reference-structured: hi_tag materialised (range_proof.rs:231-233), bases folded every round
+ *      (inner_product.rs:140-155) through bp_scalar_mul_batch / bp_fold_bases kernels and the generic MSM. */
+void bp_proto_set_path(bp_ctx* ctx, int path);
+
 /* bp_gens — the shared generators g_vec[nm], h_vec[nm], G, H that the reference passes to every
  * prove/verify call as slices (range_proof.rs:46-49, 267-270, 539-542; StatementRP,
  * range_proof_wip.rs:39-45).  Uploaded once and expanded into a fixed-base window table in HBM

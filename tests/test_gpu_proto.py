@@ -34,6 +34,30 @@ def test_bp_prove_bytes_match_golden(ctx, idx):
         gens.close()
 
 
+@pytest.mark.parametrize("idx", (0, 2))
+def test_reference_structured_rounds_give_the_same_bytes(ctx, idx):
+    """proto path 1 (hi_tag materialised, bases folded every round as inner_product.rs:140-155 does) and the
+    default fixed-table path produce the same proof bytes."""
+    ctx.set_proto_path(1)
+    try:
+        case = bp_cases()[idx]
+        gens = _gens(ctx, 0, case["n"], case["m"])
+        try:
+            proof = ctx.rangeproof_prove(gens, case["n"], _be(case["secrets"]), _be(case["blindings"]), bytes.fromhex(case["tape"]))
+            assert proof.hex() == case["proof"]
+        finally:
+            gens.close()
+        case = bpplus_cases()[idx]
+        gens = _gens(ctx, 1, case["n"], case["m"])
+        try:
+            proof = ctx.wip_rangeproof_prove(gens, case["n"], _be(case["secrets"]), _be(case["blindings"]), bytes.fromhex(case["tape"]))
+            assert proof.hex() == case["proof"]
+        finally:
+            gens.close()
+    finally:
+        ctx.set_proto_path(0)
+
+
 def test_bp_prove_c2_n64_m16(ctx):
     case = load("bp_c2_n64_m16.json")
     gens = _gens(ctx, 0, 64, 16)
