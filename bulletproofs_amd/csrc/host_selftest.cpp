@@ -6,6 +6,7 @@
 #include "ec.h"
 #include "ecmul.h"
 #include "fq.h"
+#include "hostmath.h"
 #include "sha256.h"
 
 using namespace bp;
@@ -50,6 +51,24 @@ int bpt_fq_glv(uint8_t* k1, uint8_t* k2, const uint8_t* k) {
     fq_to_be(k1, a);
     fq_to_be(k2, b);
     return (n1 ? 1 : 0) | (n2 ? 2 : 0);
+}
+// host scalar class of the protocol layer (hostmath.h: 4 x 64-bit Montgomery limbs); op: 0 mul, 1 add, 2 sub, 3 inv(a),
+// 4 neg(a), 5 a^(low 64 bits of b), 6 ((a - b) * (a + b) + a) * b - a, 7 a == b (out[31])
+void bpt_hostfq(uint8_t* out, const uint8_t* a, const uint8_t* b, int op) {
+    Fq x = Fq::from_be(a), y = Fq::from_be(b), r;
+    uint64_t e = 0;
+    for (int i = 24; i < 32; i++) e = (e << 8) | b[i];
+    switch (op) {
+        case 0: r = x * y; break;
+        case 1: r = x + y; break;
+        case 2: r = x - y; break;
+        case 3: r = x.inv(); break;
+        case 4: r = -x; break;
+        case 5: r = x.pow(e); break;
+        case 6: r = ((x - y) * (x + y) + x) * y - x; break;
+        default: r = Fq(x == y ? 1 : 0); break;
+    }
+    r.to_be(out);
 }
 void bpt_fq_reduce(uint8_t* out, const uint8_t* a) { fq_to_be(out, fq_from_be_raw(a)); }
 

@@ -16,47 +16,147 @@
 
 namespace bp {
 
-// ---- scalar mod q, plain domain ------------------------------------------------------------------
+// ---- scalar mod q on the host ---------------------------------------------------------------------
+// 4 x 64-bit limbs kept in the Montgomery domain (R = 2^256), always canonical (< q), so +, -, ==, zero
+// tests work on the representation and a product is ONE CIOS pass over unsigned __int128 (~30 ns; the
+// plain-domain 8 x 32 fq_mul of fq.h costs two passes and ~300 ns).  The prover's per-round coefficient
+// updates (ipa_prove_fixed in proto.cpp: 4nm products per round) made this the host's hot loop.
+// Bytes at the boundary are converted on the way in / out and are the reference's canonical values.
 struct Fq {
-    fq v;
-    Fq() { v = fq_zero(); }
-    explicit Fq(uint64_t x) {
-        v = fq_zero();
-        v.v[0] = (uint32_t)x;
-        v.v[1] = (uint32_t)(x >> 32);
+    uint64_t m[4];
+    typedef unsigned __int128 u128;
+    static constexpr uint64_t Q0 = 0xBFD25E8CD0364141ULL, Q1 = 0xBAAEDCE6AF48A03BULL, Q2 = 0xFFFFFFFFFFFFFFFEULL, Q3 = 0xFFFFFFFFFFFFFFFFULL;
+    static constexpr uint64_t QINV = 0x4B0DFF665588B13FULL;  // -q^-1 mod 2^64
+    static void mont_mul(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+        const uint64_t q[4] = {Q0, Q1, Q2, Q3};
+        uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 4; i++) {
+            u128 c = 0;
+            for (int j = 0; j < 4; j++) {
+                c += (u128)a[i] * b[j] + t[j];
+                t[j] = (uint64_t)c;
+                c >>= 64;
+            }
+            c += t[4];
+            t[4] = (uint64_t)c;
+            t[5] = (uint64_t)(c >> 64);
+            const uint64_t mm = t[0] * QINV;
+            c = (u128)mm * q[0] + t[0];
+            c >>= 64;
+            for (int j = 1; j < 4; j++) {
+                c += (u128)mm * q[j] + t[j];
+                t[j - 1] = (uint64_t)c;
+                c >>= 64;
+            }
+            c += t[4];
+            t[3] = (uint64_t)c;
+            t[4] = t[5] + (uint64_t)(c >> 64);
+        }
+        reduce_once(r, t, t[4]);
     }
-    static Fq from_be(const uint8_t* b) {
+    // r = (carry * 2^256 + t) mod q for a value < 2q
+    static void reduce_once(uint64_t r[4], const uint64_t t[4], uint64_t carry) {
+        const uint64_t q[4] = {Q0, Q1, Q2, Q3};
+        uint64_t s[4];
+        u128 bw = 0;
+        for (int i = 0; i < 4; i++) {
+            u128 d = (u128)t[i] - q[i] - (uint64_t)bw;
+            s[i] = (uint64_t)d;
+            bw = (d >> 64) & 1;
+        }
+        const bool take = carry || !bw;
+        for (int i = 0; i < 4; i++) r[i] = take ? s[i] : t[i];
+    }
+    Fq() { m[0] = m[1] = m[2] = m[3] = 0; }
+    explicit Fq(uint64_t x) {
+        const uint64_t R2[4] = {0x896CF21467D7D140ULL, 0x741496C20E7CF878ULL, 0xE697F5E45BCD07C6ULL, 0x9D671CD581C69BC5ULL};
+        const uint64_t a[4] = {x, 0, 0, 0};
+        mont_mul(m, a, R2);
+    }
+    static Fq from_be(const uint8_t* b) {  // any 256-bit value, reduced like Scalar::from(&BigInt)
+        const uint64_t R2[4] = {0x896CF21467D7D140ULL, 0x741496C20E7CF878ULL, 0xE697F5E45BCD07C6ULL, 0x9D671CD581C69BC5ULL};
+        fq k = fq_from_be_reduce(b);
+        uint64_t a[4];
+        for (int i = 0; i < 4; i++) a[i] = (uint64_t)k.v[2 * i] | ((uint64_t)k.v[2 * i + 1] << 32);
         Fq r;
-        r.v = fq_from_be_reduce(b);
+        mont_mul(r.m, a, R2);
         return r;
     }
-    void to_be(uint8_t* b) const { fq_to_be(b, v); }
-    bool is_zero() const { return fq_is_zero(v); }
-    bool operator==(const Fq& o) const { return fq_eq(v, o.v); }
+    void to_be(uint8_t* b) const {
+        const uint64_t one[4] = {1, 0, 0, 0};
+        uint64_t a[4];
+        mont_mul(a, m, one);
+        fq k;
+        for (int i = 0; i < 4; i++) {
+            k.v[2 * i] = (uint32_t)a[i];
+            k.v[2 * i + 1] = (uint32_t)(a[i] >> 32);
+        }
+        fq_to_be(b, k);
+    }
+    bool is_zero() const { return (m[0] | m[1] | m[2] | m[3]) == 0; }
+    bool operator==(const Fq& o) const { return ((m[0] ^ o.m[0]) | (m[1] ^ o.m[1]) | (m[2] ^ o.m[2]) | (m[3] ^ o.m[3])) == 0; }
     Fq operator+(const Fq& o) const {
+        uint64_t t[4];
+        u128 c = 0;
+        for (int i = 0; i < 4; i++) {
+            c += (u128)m[i] + o.m[i];
+            t[i] = (uint64_t)c;
+            c >>= 64;
+        }
         Fq r;
-        r.v = fq_add(v, o.v);
+        reduce_once(r.m, t, (uint64_t)c);
         return r;
     }
     Fq operator-(const Fq& o) const {
+        const uint64_t q[4] = {Q0, Q1, Q2, Q3};
         Fq r;
-        r.v = fq_sub(v, o.v);
+        u128 bw = 0;
+        for (int i = 0; i < 4; i++) {
+            u128 d = (u128)m[i] - o.m[i] - (uint64_t)bw;
+            r.m[i] = (uint64_t)d;
+            bw = (d >> 64) & 1;
+        }
+        if (bw) {
+            u128 c = 0;
+            for (int i = 0; i < 4; i++) {
+                c += (u128)r.m[i] + q[i];
+                r.m[i] = (uint64_t)c;
+                c >>= 64;
+            }
+        }
         return r;
     }
-    Fq operator-() const {
-        Fq r;
-        r.v = fq_neg(v);
-        return r;
-    }
+    Fq operator-() const { return Fq() - *this; }
     Fq operator*(const Fq& o) const {
         Fq r;
-        r.v = fq_mul(v, o.v);
+        mont_mul(r.m, m, o.m);
         return r;
     }
-    Fq inv() const {  // caller guarantees non-zero (the reference unwraps)
-        Fq r;
-        r.v = fq_inv(v);
+    Fq sqr_n(int n) const {
+        Fq r = *this;
+        for (int i = 0; i < n; i++) r = r * r;
         return r;
+    }
+    // a^(q-2): the addition chain of fq_mont_inv (fq.h): 2^127 - 1 ones, then a sliding window over the low
+    // 129 bits.  Caller guarantees non-zero (the reference unwraps).
+    Fq inv() const {
+        static const uint8_t nsqr[26] = {5, 3, 4, 4, 5, 2, 5, 6, 5, 4, 3, 6, 10, 4, 5, 4, 5, 6, 4, 5, 6, 10, 4, 9, 4, 1};
+        static const uint8_t odd[26] = {11, 5, 5, 7, 13, 3, 7, 13, 11, 13, 1, 5, 7, 7, 15, 15, 9, 11, 13, 3, 13, 13, 9, 9, 15, 1};
+        Fq tbl[8];
+        tbl[0] = *this;
+        Fq a2 = *this * *this;
+        for (int i = 1; i < 8; i++) tbl[i] = tbl[i - 1] * a2;
+        Fq x3 = tbl[3];
+        Fq x6 = x3.sqr_n(3) * x3;
+        Fq x12 = x6.sqr_n(6) * x6;
+        Fq x24 = x12.sqr_n(12) * x12;
+        Fq x48 = x24.sqr_n(24) * x24;
+        Fq x96 = x48.sqr_n(48) * x48;
+        Fq x120 = x96.sqr_n(24) * x24;
+        Fq x126 = x120.sqr_n(6) * x6;
+        Fq acc = x126 * x126 * *this;
+        for (int s = 0; s < 26; s++) acc = acc.sqr_n(nsqr[s]) * tbl[odd[s] >> 1];
+        return acc;
     }
     Fq pow(uint64_t e) const {
         Fq r(1), b = *this;

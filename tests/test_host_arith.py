@@ -84,6 +84,31 @@ def test_fq(L):
     assert call1(L.bpt_fq_reduce, Q) == 0
 
 
+def test_host_scalar_class(L):
+    """hostmath.h `Fq` (4 x 64-bit Montgomery limbs: the protocol layer's scalars) against Python ints."""
+    rng = random.Random(18)
+    edge = [0, 1, 2, Q - 1, Q - 2, (Q - 1) // 2, 2**255, 2**128, 2**64 - 1, 2**64, 2**192 - 1, 2**256 - 1, Q, Q + 1]
+    vals = edge + [rng.randrange(2**256) for _ in range(80)]
+
+    def hf(a, b, op):
+        o = ctypes.create_string_buffer(32)
+        L.bpt_hostfq(o, b32(a), b32(b), op)
+        return int.from_bytes(o.raw, "big")
+
+    for a in vals:
+        for b in rng.sample(vals, 6) + edge[:6]:
+            assert hf(a, b, 0) == a * b % Q
+            assert hf(a, b, 1) == (a + b) % Q
+            assert hf(a, b, 2) == (a - b) % Q
+            assert hf(a, b, 6) == (((a - b) * (a + b) + a) * b - a) % Q
+            assert hf(a, b, 7) == (1 if (a - b) % Q == 0 else 0)
+        assert hf(a, 0, 4) == (-a) % Q
+        assert hf(a, 65537, 5) == pow(a, 65537, Q)
+        assert hf(a, 2**64 - 1, 5) == pow(a, 2**64 - 1, Q)
+        if a % Q:
+            assert hf(a, 0, 3) == pow(a, -1, Q)
+
+
 def test_ec(L, oracle_c):
     rng = random.Random(9)
 
