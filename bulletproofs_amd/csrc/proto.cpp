@@ -510,6 +510,44 @@ int ipa_verify(bp_ctx* ctx, const Ipa& p, const affine_mem* G0, const affine_mem
     return BP_OK;
 }
 
+// InnerProductArg::verify (:171-244) over the unfolded generators: the recursion's final comparison
+//   a G^(k)[0] + b H^(k)[0] + ab ux  ==  P + sum_j (x_j^2 L_j + x_j^-2 R_j)          (:220-238)
+// with G^(k)[0] = sum_t cG[t] g_t and H^(k)[0] = sum_t cH[t] y^-t h_t, the coefficient products of
+// ipa_prove_fixed.  Two concurrent jobs instead of k rounds of base folding.
+int ipa_verify_fixed(bp_ctx* ctx, const bp_gens* g, const Ipa& p, const std::vector<Fq>& yinv, const Fq& xu, const Pt& ux, const Pt& P, bool& ok) {
+    const size_t nm = g->nm, iG = 2 * nm;
+    ok = false;
+    int k = 0;
+    while (((size_t)1 << k) < nm) k++;
+    if (p.L.size() < (size_t)k || p.R.size() < (size_t)k) return BP_OK;  // the reference would index out of bounds and panic
+    std::vector<Fq> cG(nm, Fq(1)), cH(yinv);
+    std::vector<FbJob> jobs(2);
+    jobs[1].extra(P, Fq(1));
+    size_t n = nm;
+    for (int j = 0; j < k; j++, n /= 2) {
+        Fq x = Transcript().point(p.L[j].b).point(p.R[j].b).point(ux.b).result_scalar();
+        if (x.is_zero()) return BP_OK;
+        Fq xi = x.inv();
+        const size_t h = n / 2;
+        for (size_t t = 0; t < nm; t++) {
+            const bool lower = (t & (n - 1)) < h;
+            cG[t] = cG[t] * (lower ? xi : x);  // G_new = x^-1 G_L + x G_R   (:203-209)
+            cH[t] = cH[t] * (lower ? x : xi);  // H_new = x H_L + x^-1 H_R   (:212-218)
+        }
+        jobs[1].extra(p.L[j], x * x);
+        jobs[1].extra(p.R[j], xi * xi);
+    }
+    for (size_t t = 0; t < nm; t++) {
+        jobs[0].gen(t, p.a * cG[t]);
+        jobs[0].gen(nm + t, p.b * cH[t]);
+    }
+    jobs[0].gen(iG, p.a * p.b * xu);
+    Pt r[2];
+    RC(fbmsm(ctx, g, jobs, r));
+    ok = r[0] == r[1];
+    return BP_OK;
+}
+
 // ---- proof (de)serialisation (canonical encoding, oracle/encoding.py) -----------------------------
 struct BpProof {
     Pt A, S, T1, T2;
@@ -898,6 +936,8 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
     const Pt &left = res[0], &right = res[1], &P = res[2];
     if (mode == 1) {
         ok = chal_ok && res[3] == P;
+    } else if (ctx->proto_path != 1) {
+        RC(ipa_verify_fixed(ctx, gens, pf.ipa, yinv, xu, ux, P, ok));
     } else {
         RC(ctx->proto[4].reserve(nm * sizeof(affine_mem)));
         affine_mem* hi_tag = (affine_mem*)ctx->proto[4].p;

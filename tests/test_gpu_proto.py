@@ -87,6 +87,23 @@ def test_bp_verify_modes_agree_with_oracle(ctx, idx):
         gens.close()
 
 
+@pytest.mark.parametrize("idx", (0, 1))
+def test_recursive_verify_with_folded_bases(ctx, idx):
+    """proto path 1: `verify` folds the bases every round like inner_product.rs:171-244; same verdicts."""
+    case = bp_cases()[idx]
+    n, m = case["n"], case["m"]
+    gens = _gens(ctx, 0, n, m)
+    ctx.set_proto_path(1)
+    try:
+        items = [(case["proof"], case["commitments"], case["verdict"])] + [(t["proof"], t["commitments"], t["verdict"]) for t in case["tampered"]]
+        for pf, cm, want in items:
+            coms = b"".join(bytes.fromhex(c) for c in cm)
+            assert ctx.rangeproof_verify(gens, n, m, bytes.fromhex(pf), coms, 0) == VERDICT_CODE[want], want
+    finally:
+        ctx.set_proto_path(0)
+        gens.close()
+
+
 @pytest.mark.parametrize("idx", range(4))
 def test_bpplus_prove_and_verify(ctx, idx):
     case = bpplus_cases()[idx]
