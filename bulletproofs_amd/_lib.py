@@ -30,6 +30,8 @@ EXPORTED_SYMBOLS = [
     "bp_gens_table_bytes",
     "bp_rangeproof_verify_batch",
     "bp_rangeproof_verify_batch_device",
+    "bp_rangeproof_verify_batch_rlc",
+    "bp_rangeproof_verify_batch_rlc_device",
     "bp_ctx_sync",
     "bp_verify_set_lanes",
     "bp_scalar_mul_batch",
@@ -97,6 +99,10 @@ def lib():
     L.bp_rangeproof_verify_batch.restype = i32
     L.bp_rangeproof_verify_batch_device.argtypes = [vp, vp, i32, i32, vp, sz, vp, sz, vp]
     L.bp_rangeproof_verify_batch_device.restype = i32
+    L.bp_rangeproof_verify_batch_rlc.argtypes = [vp, vp, i32, i32, cp, sz, cp, sz, cp, cp, ctypes.POINTER(i32)]
+    L.bp_rangeproof_verify_batch_rlc.restype = i32
+    L.bp_rangeproof_verify_batch_rlc_device.argtypes = [vp, vp, i32, i32, vp, sz, vp, sz, cp, vp, ctypes.POINTER(i32)]
+    L.bp_rangeproof_verify_batch_rlc_device.restype = i32
     L.bp_ctx_sync.argtypes = [vp]
     L.bp_ctx_sync.restype = i32
     L.bp_verify_set_lanes.argtypes = [vp, i32]
@@ -234,6 +240,27 @@ class Context:
         out = ctypes.create_string_buffer(max(nproofs, 1))
         _check(lib().bp_rangeproof_verify_batch(self._h, gens._h, n_bits, m, proofs, proof_len, coms_xy, nproofs, out))
         return list(out.raw[:nproofs])
+
+    def rangeproof_verify_batch_rlc(self, gens, n_bits, m, proofs, coms_xy, seed):
+        """Same verdicts through one random-linear-combination MSM (per-proof fallback when it fails)
+        -> (list of verdict codes, used_fallback)."""
+        proofs, coms_xy, seed = bytes(proofs), bytes(coms_xy), bytes(seed)
+        nm = n_bits * m
+        k = max(nm.bit_length() - 1, 0)
+        proof_len = 292 + 66 * k
+        nproofs = len(proofs) // proof_len if proof_len else 0
+        if nproofs * proof_len != len(proofs) or len(coms_xy) != nproofs * m * 64 or len(seed) != 32:
+            raise BpError(BP_EINVAL, "proofs/commitments/seed length mismatch")
+        out = ctypes.create_string_buffer(max(nproofs, 1))
+        fb = ctypes.c_int32(0)
+        _check(lib().bp_rangeproof_verify_batch_rlc(self._h, gens._h, n_bits, m, proofs, proof_len, coms_xy, nproofs, seed, out, ctypes.byref(fb)))
+        return list(out.raw[:nproofs]), bool(fb.value)
+
+    def rangeproof_verify_batch_rlc_device(self, gens, n_bits, m, d_proofs, proof_len, d_coms, nproofs, seed, d_verdicts):
+        fb = ctypes.c_int32(0)
+        _check(lib().bp_rangeproof_verify_batch_rlc_device(self._h, gens._h, n_bits, m, d_proofs, proof_len, d_coms, nproofs, bytes(seed),
+                                                           d_verdicts, ctypes.byref(fb)))
+        return bool(fb.value)
 
     def scalar_mul_batch(self, points_xy, scalars_be):
         n = len(scalars_be) // 32

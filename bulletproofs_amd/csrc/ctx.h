@@ -55,6 +55,7 @@ struct bp_ctx {
     bp::DevBuf scratch[8];
     bp::DevBuf vartab, fixres;
     bp::DevBuf proto[6];  // protocol layer (proto.cpp): folded bases, hi_tag, staging
+    bp::DevBuf rlc[3];    // random-linear-combination batch verifier (rlc_kernels.hip): weights, MSM scalars, misc
     bp::DevBuf fb[3];     // fixed-table MSM of the protocol layer (fbmsm.hip): inputs, digits, partials + output
     void* h_pin = nullptr;  // pinned host staging for the protocol layer's small uploads / read-backs (grow-only)
     size_t h_pin_cap = 0;
@@ -74,6 +75,7 @@ struct bp_ctx {
         fixres.release();
         for (auto& s : proto) s.release();
         for (auto& s : fb) s.release();
+        for (auto& s : rlc) s.release();
         if (h_pin) (void)hipHostFree(h_pin);
         h_pin = nullptr;
         h_pin_cap = 0;

@@ -179,11 +179,11 @@ int bp_profile_get(bp_ctx* ctx, int kernel_id, double* total_ms, long* launches)
     return BP_OK;
 }
 
-int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
-                                      const void* d_coms_xy, size_t nproofs, void* d_verdicts) {
+// argument checks shared by the batch verifiers: BP_EINVAL where the reference asserts (range_proof.rs:556-562)
+static int check_batch_args(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len, const void* d_coms_xy,
+                            size_t nproofs, void* d_verdicts, int* k_out) {
     if (!ctx || !gens || n_bits <= 0 || n_bits > 128 || m <= 0) return BP_EINVAL;
-    if (nproofs == 0) return BP_OK;
-    if (!d_proofs || !d_coms_xy || !d_verdicts) return BP_EINVAL;
+    if (nproofs && (!d_proofs || !d_coms_xy || !d_verdicts)) return BP_EINVAL;
     size_t nm = (size_t)n_bits * m;
     if (nm != gens->nm || (nm & (nm - 1)) != 0 || gens->device != ctx->device) {
         set_error_msg("n_bits*m must be a power of two and equal the generators' nm (range_proof.rs:556-558)");
@@ -195,7 +195,24 @@ int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bi
         set_error_msg("proof_len != 292 + 66*log2(nm)");
         return BP_EINVAL;
     }
+    *k_out = k;
+    return BP_OK;
+}
+
+static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, const void* d_proofs, size_t proof_len,
+                                      const void* d_coms_xy, size_t nproofs, void* d_verdicts);
+
+int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
+                                      const void* d_coms_xy, size_t nproofs, void* d_verdicts) {
+    int k = 0;
+    int rc = check_batch_args(ctx, gens, n_bits, m, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, &k);
+    if (rc != BP_OK || nproofs == 0) return rc;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    return verify_batch_device_nolock(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts);
+}
+
+static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, const void* d_proofs, size_t proof_len,
+                                      const void* d_coms_xy, size_t nproofs, void* d_verdicts) {
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = ctx->stream;
     const int NPT = 4 + 2 * k + m, NV = 3 + 2 * k + m;
@@ -221,7 +238,7 @@ int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bi
            "bpv_decompress");
     prof_mark(ctx, 1);
     HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
-                                      gens->d_table, gens->c, gens->W, (int16_t*)b_dig.p, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
+                                      gens->d_table, gens->c, gens->W, (int16_t*)b_dig.p, nullptr, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
                                       (int*)b_bad.p, st),
            "bpv_scalars");
     prof_mark(ctx, 2);
@@ -240,6 +257,93 @@ int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bi
         ctx->prof_ids[2] = BP_PROF_BPV_MSM;
         ctx->prof_n = 3;
     }
+    return BP_OK;
+}
+
+// Random-linear-combination batch verification (rlc_kernels.hip).  Synchronous: returns with the verdicts
+// written.  *used_fallback (nullable) = 1 when the combined check failed and the per-proof kernel decided.
+int bp_rangeproof_verify_batch_rlc_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
+                                          const void* d_coms_xy, size_t nproofs, const uint8_t seed[32], void* d_verdicts, int* used_fallback) {
+    int k = 0;
+    int rc = check_batch_args(ctx, gens, n_bits, m, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, &k);
+    if (rc != BP_OK) return rc;
+    if (!seed) return BP_EINVAL;
+    if (used_fallback) *used_fallback = 0;
+    if (nproofs == 0) return BP_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t st = ctx->stream;
+    const int NPT = 4 + 2 * k + m, NV = 3 + 2 * k + m, np = gens->np, W = gens->W;
+    if (nproofs * (size_t)NPT >= ((size_t)1 << 30)) {
+        set_error_msg("rlc batch too large for one MSM");
+        return BP_EINVAL;
+    }
+    DevBuf &b_pts = ctx->scratch[0], &b_bad = ctx->scratch[1], &b_scF = ctx->scratch[2], &b_var = ctx->scratch[3], &b_s = ctx->scratch[4];
+    DevBuf &b_rho = ctx->rlc[0], &b_scbe = ctx->rlc[1], &b_misc = ctx->rlc[2];
+    const size_t nchunks = rlc_colsum_chunks(nproofs);
+    if ((rc = b_pts.reserve(nproofs * NPT * sizeof(affine_mem))) != BP_OK) return rc;
+    if ((rc = b_bad.reserve(nproofs * sizeof(int))) != BP_OK) return rc;
+    if ((rc = b_scF.reserve(nproofs * (size_t)np * sizeof(fqm))) != BP_OK) return rc;
+    if ((rc = b_var.reserve(nproofs * NV * sizeof(fq))) != BP_OK) return rc;
+    if ((rc = b_s.reserve(nproofs * (bpv_chal_count(k) + bpv_cst_count(k, m)) * sizeof(fq))) != BP_OK) return rc;
+    if ((rc = ctx->fixres.reserve(nproofs * 2 * (sizeof(xyzz) + sizeof(affine_mem)))) != BP_OK) return rc;
+    if ((rc = b_rho.reserve(nproofs * sizeof(fqm))) != BP_OK) return rc;
+    if ((rc = b_scbe.reserve(nproofs * (size_t)NPT * 32)) != BP_OK) return rc;
+    // misc: chunk sums | fixed scalars (BE) | seed | generator index 0..np-1 | term offsets {0, np} | extras offsets {0, 0} |
+    //       fixed-part result (BE) | its limb form | all_ok
+    const size_t o_part = 0, o_fbe = o_part + (size_t)np * nchunks * sizeof(fqm), o_seed = o_fbe + (size_t)np * 32, o_gidx = o_seed + 32,
+                 o_toff = o_gidx + (size_t)np * 4, o_xoff = o_toff + 8, o_res = (o_xoff + 8 + 63) / 64 * 64, o_init = o_res + 64,
+                 o_ok = o_init + sizeof(affine_mem), misc_bytes = o_ok + 64;
+    if ((rc = b_misc.reserve(misc_bytes)) != BP_OK) return rc;
+    if ((rc = ctx->fb[1].reserve((size_t)np * W * sizeof(int16_t))) != BP_OK) return rc;
+    int nblk = (int)(((size_t)np * W + 255) / 256);
+    if (nblk > 128) nblk = 128;
+    if ((rc = ctx->fb[2].reserve((size_t)nblk * sizeof(xyzz))) != BP_OK) return rc;
+    fq* d_chal = (fq*)b_s.p;
+    fq* d_cst = d_chal + nproofs * bpv_chal_count(k);
+    xyzz* d_fixres = (xyzz*)ctx->fixres.p;
+    affine_mem* d_fixaff = (affine_mem*)(d_fixres + nproofs * 2);
+    uint8_t* misc = (uint8_t*)b_misc.p;
+    std::vector<uint32_t> h_idx((size_t)np + 4);
+    for (int i = 0; i < np; i++) h_idx[i] = (uint32_t)i;
+    h_idx[np] = 0;
+    h_idx[np + 1] = (uint32_t)np;
+    h_idx[np + 2] = 0;
+    h_idx[np + 3] = 0;
+    HIPCHK(hipMemcpyAsync(misc + o_seed, seed, 32, hipMemcpyHostToDevice, st), "memcpy seed");
+    HIPCHK(hipMemcpyAsync(misc + o_gidx, h_idx.data(), ((size_t)np + 4) * 4, hipMemcpyHostToDevice, st), "memcpy index");
+    HIPCHK(hipMemsetAsync(b_bad.p, 0, nproofs * sizeof(int), st), "memset");
+    HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), st), "memset");
+    HIPCHK(launch_bpv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine_mem*)b_pts.p, (int*)b_bad.p, st),
+           "bpv_decompress");
+    HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
+                                      gens->d_table, gens->c, W, nullptr, (fqm*)b_scF.p, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
+                                      (int*)b_bad.p, st),
+           "bpv_scalars");
+    HIPCHK(launch_rlc_weights(misc + o_seed, nproofs, (const int*)b_bad.p, (fqm*)b_rho.p, st), "rlc_weights");
+    HIPCHK(launch_rlc_var_scalars(k, m, nproofs, (const fqm*)b_rho.p, (const fq*)b_var.p, (uint8_t*)b_scbe.p, st), "rlc_var_scalars");
+    HIPCHK(launch_rlc_colsum(np, nproofs, (const fqm*)b_rho.p, (const fqm*)b_scF.p, (const int*)b_bad.p, (fqm*)(misc + o_part), misc + o_fbe, st),
+           "rlc_colsum");
+    // the 2nm+2 generator terms: one fixed-base MSM from the table; its value is the init of the big MSM
+    HIPCHK(launch_mb_digits(misc + o_fbe, (size_t)np, gens->c, W, (int16_t*)ctx->fb[1].p, st), "digits");
+    HIPCHK(launch_fb_msm(1, gens->d_table, W, gens->NB, (const int16_t*)ctx->fb[1].p, (const uint32_t*)(misc + o_gidx),
+                         (const uint32_t*)(misc + o_toff), nullptr, nullptr, (const uint32_t*)(misc + o_xoff), nblk, 0, nullptr,
+                         (xyzz*)ctx->fb[2].p, misc + o_res, st),
+           "fb_msm");
+    HIPCHK(launch_ingest_points(misc + o_res, (affine_mem*)(misc + o_init), 1, ctx->d_err, st), "ingest");
+    if ((rc = msm_on_device(ctx, (const affine_mem*)b_pts.p, (const uint8_t*)b_scbe.p, nproofs * (size_t)NPT, (const affine_mem*)(misc + o_init))) != BP_OK)
+        return rc;
+    HIPCHK(launch_rlc_verdicts(nproofs, (const uint8_t*)ctx->result.p + sizeof(affine_mem), (const int*)b_bad.p, (uint8_t*)d_verdicts,
+                               (int*)(misc + o_ok), st),
+           "rlc_verdicts");
+    int all_ok = 0;
+    HIPCHK(hipMemcpyAsync(&all_ok, misc + o_ok, sizeof(int), hipMemcpyDeviceToHost, st), "memcpy flag");
+    HIPCHK(hipStreamSynchronize(st), "sync");
+    if (all_ok) return BP_OK;
+    // some well-formed proof is invalid: the per-proof kernel decides (identical verdicts by construction)
+    if (used_fallback) *used_fallback = 1;
+    if ((rc = verify_batch_device_nolock(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts)) != BP_OK) return rc;
+    HIPCHK(hipStreamSynchronize(st), "sync");
     return BP_OK;
 }
 
@@ -314,25 +418,48 @@ int bp_msm_batch(bp_ctx* ctx, const bp_gens* gens, const bp_msm_job* jobs, size_
     return BP_OK;
 }
 
+// host buffers -> device staging (scratch[5..7]); shared by the two host-pointer batch verifiers
+static int stage_batch(bp_ctx* ctx, const uint8_t* proofs, size_t proof_len, const uint8_t* coms_xy, int m, size_t nproofs, void** d_p, void** d_c,
+                       void** d_v) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    int rc;
+    if ((rc = ctx->scratch[5].reserve(nproofs * proof_len)) != BP_OK) return rc;
+    if ((rc = ctx->scratch[6].reserve(nproofs * (size_t)m * 64)) != BP_OK) return rc;
+    if ((rc = ctx->scratch[7].reserve(nproofs)) != BP_OK) return rc;
+    *d_p = ctx->scratch[5].p;
+    *d_c = ctx->scratch[6].p;
+    *d_v = ctx->scratch[7].p;
+    HIPCHK(hipMemcpyAsync(*d_p, proofs, nproofs * proof_len, hipMemcpyHostToDevice, ctx->stream), "memcpy proofs");
+    HIPCHK(hipMemcpyAsync(*d_c, coms_xy, nproofs * (size_t)m * 64, hipMemcpyHostToDevice, ctx->stream), "memcpy coms");
+    return BP_OK;
+}
+
+int bp_rangeproof_verify_batch_rlc(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
+                                   const uint8_t* coms_xy, size_t nproofs, const uint8_t seed[32], uint8_t* verdicts, int* used_fallback) {
+    if (!ctx || !gens || m <= 0 || !seed) return BP_EINVAL;
+    if (used_fallback) *used_fallback = 0;
+    if (nproofs == 0) return BP_OK;
+    if (!proofs || !coms_xy || !verdicts) return BP_EINVAL;
+    void *d_p, *d_c, *d_v;
+    int rc = stage_batch(ctx, proofs, proof_len, coms_xy, m, nproofs, &d_p, &d_c, &d_v);
+    if (rc != BP_OK) return rc;
+    rc = bp_rangeproof_verify_batch_rlc_device(ctx, gens, n_bits, m, d_p, proof_len, d_c, nproofs, seed, d_v, used_fallback);
+    if (rc != BP_OK) return rc;
+    std::vector<uint8_t> tmp(nproofs);
+    HIPCHK(hipMemcpyAsync(tmp.data(), d_v, nproofs, hipMemcpyDeviceToHost, ctx->stream), "memcpy verdicts");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "sync");
+    memcpy(verdicts, tmp.data(), nproofs);
+    return BP_OK;
+}
+
 int bp_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
                                const uint8_t* coms_xy, size_t nproofs, uint8_t* verdicts) {
     if (!ctx || !gens || m <= 0) return BP_EINVAL;
     if (nproofs == 0) return BP_OK;
     if (!proofs || !coms_xy || !verdicts) return BP_EINVAL;
     void *d_p, *d_c, *d_v;
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-        int rc;
-        if ((rc = ctx->scratch[5].reserve(nproofs * proof_len)) != BP_OK) return rc;
-        if ((rc = ctx->scratch[6].reserve(nproofs * (size_t)m * 64)) != BP_OK) return rc;
-        if ((rc = ctx->scratch[7].reserve(nproofs)) != BP_OK) return rc;
-        d_p = ctx->scratch[5].p;
-        d_c = ctx->scratch[6].p;
-        d_v = ctx->scratch[7].p;
-        HIPCHK(hipMemcpyAsync(d_p, proofs, nproofs * proof_len, hipMemcpyHostToDevice, ctx->stream), "memcpy proofs");
-        HIPCHK(hipMemcpyAsync(d_c, coms_xy, nproofs * (size_t)m * 64, hipMemcpyHostToDevice, ctx->stream), "memcpy coms");
-    }
+    if (int rcs = stage_batch(ctx, proofs, proof_len, coms_xy, m, nproofs, &d_p, &d_c, &d_v)) return rcs;
     int rc = bp_rangeproof_verify_batch_device(ctx, gens, n_bits, m, d_p, proof_len, d_c, nproofs, d_v);
     if (rc != BP_OK) return rc;
     std::vector<uint8_t> tmp(nproofs);

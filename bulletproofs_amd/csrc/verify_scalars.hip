@@ -312,8 +312,8 @@ __global__ __launch_bounds__(64) void k_bpv_hash2(int k, int m, size_t nproofs, 
 #define BPV_MAXK 16
 
 __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
-                                                   const fq* __restrict__ chal, int c, int W, int16_t* __restrict__ digF, fq* __restrict__ varS,
-                                                   fqm* __restrict__ cst, int* __restrict__ bad) {
+                                                   const fq* __restrict__ chal, int c, int W, int16_t* __restrict__ digF, fqm* __restrict__ scF,
+                                                   fq* __restrict__ varS, fqm* __restrict__ cst, int* __restrict__ bad) {
     size_t pr = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (pr >= nproofs || bad[pr]) return;
     const int nm = n_bits * m;
@@ -398,9 +398,14 @@ __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ p
     fqm abm = fqm_mul(a_m, b_m);
     fqm sG = fqm_add(fqm_mul(xu_m, fqm_sub(abm, tx_m)), fqm_mul(c_m, fqm_sub(delta, tx_m)));
     fqm sH = fqm_sub(miu_m, fqm_mul(c_m, taux_m));
-    int16_t* dg = digF + pr * (size_t)(2 * nm + 2) * W;
-    store_digits(fqm_to_fq(sG), c, W, dg + (size_t)(2 * nm) * W);
-    store_digits(fqm_to_fq(sH), c, W, dg + (size_t)(2 * nm + 1) * W);
+    if (scF) {  // random-linear-combination mode (rlc_kernels.hip): the scalars themselves, Montgomery form
+        scF[pr * (size_t)(2 * nm + 2) + 2 * nm] = sG;
+        scF[pr * (size_t)(2 * nm + 2) + 2 * nm + 1] = sH;
+    } else {
+        int16_t* dg = digF + pr * (size_t)(2 * nm + 2) * W;
+        store_digits(fqm_to_fq(sG), c, W, dg + (size_t)(2 * nm) * W);
+        store_digits(fqm_to_fq(sH), c, W, dg + (size_t)(2 * nm + 1) * W);
+    }
     // S : -x ; T1 : c x ; T2 : c x^2                                           :727, 739-740
     vs[0] = fqm_to_fq(fqm_neg(x_m));
     fqm cx = fqm_mul(c_m, x_m);
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ p
 // One lane per (proof, i): g_i : a s_i + z ; h_i : y^-i (b s_i^-1 - d_i) - z          :670-705
 // s_i = prod_t (bit_t(i) ? x_{k-1-t} : x_{k-1-t}^-1), s_i^-1 = s_{nm-1-i}; d_i = z^(2+i/n) 2^(i mod n).
 __global__ __launch_bounds__(256) void k_bpv_vec(int n_bits, int m, int k, size_t nproofs, const fqm* __restrict__ cst, int c, int W,
-                                                 int16_t* __restrict__ digF, const int* __restrict__ bad) {
+                                                 int16_t* __restrict__ digF, fqm* __restrict__ scF, const int* __restrict__ bad) {
     const int nm = n_bits * m;
     size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= nproofs * (size_t)nm) return;
@@ -441,6 +446,11 @@ __global__ __launch_bounds__(256) void k_bpv_vec(int n_bits, int m, int k, size_
     two_r.v[r >> 5] = 1u << (r & 31);
     fqm d_i = fqm_mul(fqm_from_fq(two_r), cs[CS_ZPOW(k) + i / n_bits]);
     fqm hs = fqm_sub(fqm_mul(yip, fqm_sub(fqm_mul(cs[CS_B], sinv), d_i)), z_m);
+    if (scF) {
+        scF[pr * (size_t)(2 * nm + 2) + i] = gs;
+        scF[pr * (size_t)(2 * nm + 2) + nm + i] = hs;
+        return;
+    }
     int16_t* dg = digF + pr * (size_t)(2 * nm + 2) * W;
     store_digits(fqm_to_fq(gs), c, W, dg + (size_t)i * W);
     store_digits(fqm_to_fq(hs), c, W, dg + (size_t)(nm + i) * W);
@@ -452,7 +462,7 @@ size_t bpv_chal_count(int k) { return CH_COUNT(k); }
 size_t bpv_cst_count(int k, int m) { return ((size_t)CS_COUNT(k, m) * sizeof(fqm) + sizeof(fq) - 1) / sizeof(fq); }
 
 hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
-                                      const affine_mem* gens, const affine_mem* table, int c, int W, int16_t* digF, fq* varS, fq* chal,
+                                      const affine_mem* gens, const affine_mem* table, int c, int W, int16_t* digF, fqm* scF, fq* varS, fq* chal,
                                       fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st) {
     const int nm = n_bits * m;
     hipLaunchKernelGGL(k_bpv_hash1, dim3((unsigned)((nproofs * 4 + 63) / 64)), dim3(64), 0, st, proofs, proof_len, k, m, nm, nproofs, pts, gens,
@@ -461,10 +471,9 @@ hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, i
     hipLaunchKernelGGL(k_bpv_fixinv, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, nproofs, fixres, fixaff, bad);
     hipLaunchKernelGGL(k_bpv_hash2, dim3((unsigned)((nproofs * (k + 1) + 63) / 64)), dim3(64), 0, st, k, m, nproofs, pts, fixaff, chal, bad);
     hipLaunchKernelGGL(k_bpv_consts, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W,
-                       digF, varS, reinterpret_cast<fqm*>(cst), bad);
+                       digF, scF, varS, reinterpret_cast<fqm*>(cst), bad);
     hipLaunchKernelGGL(k_bpv_vec, dim3((unsigned)((nproofs * (size_t)nm + 255) / 256)), dim3(256), 0, st, n_bits, m, k, nproofs,
-                       reinterpret_cast<const fqm*>(cst), c, W, digF,
-                       bad);
+                       reinterpret_cast<const fqm*>(cst), c, W, digF, scF, bad);
     return hipGetLastError();
 }
 

@@ -136,6 +136,21 @@ int bp_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int
 int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
                                       const void* d_coms_xy, size_t nproofs, void* d_verdicts);
 int bp_ctx_sync(bp_ctx* ctx);
+
+/* bp_rangeproof_verify_batch_rlc(_device) — the same verdicts as bp_rangeproof_verify_batch, through ONE
+ * random-linear-combination check for the whole batch (no counterpart in the reference,
+ * which verifies one proof per call): with per-proof 128-bit weights rho_j derived from `seed`,
+ *     sum_j rho_j * (lhs_j - A_j) == O      (lhs_j - A_j == O is range_proof.rs:777 for proof j)
+ * is evaluated as one fixed-base MSM over the 2nm+2 generators (scalars summed over the batch mod q) plus one
+ * large Pippenger MSM over the 4+2k+m proof points of every proof.  If it holds, every well-formed proof is
+ * valid (a batch containing an invalid proof passes with probability ~2^-128 over the seed); if it fails the
+ * per-proof kernel runs, so the verdict bytes are always those of bp_rangeproof_verify_batch.  Malformed
+ * proofs get verdict 255 and are left out of the combination.  `seed`: 32 bytes of caller randomness chosen
+ * AFTER the proofs are fixed (host pointer).  Synchronous.  *used_fallback (nullable) reports which path decided. */
+int bp_rangeproof_verify_batch_rlc(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
+                                   const uint8_t* coms_xy, size_t nproofs, const uint8_t seed[32], uint8_t* verdicts, int* used_fallback);
+int bp_rangeproof_verify_batch_rlc_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
+                                          const void* d_coms_xy, size_t nproofs, const uint8_t seed[32], void* d_verdicts, int* used_fallback);
 /* Tuning knob: lanes per proof in the verifier's MSM kernel (4, 8, 16, 32 or 64; 0 = chosen by batch size). */
 void bp_verify_set_lanes(bp_ctx* ctx, int lanes);
 

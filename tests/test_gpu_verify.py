@@ -79,3 +79,80 @@ def test_verify_rejects_bad_sizes(ctx):
         assert e.value.code == -1
     finally:
         gens.close()
+
+
+# ---- random-linear-combination batch verification (bp_rangeproof_verify_batch_rlc) ------------------
+def _c3(ctx, window_bits=8):
+    b = load("bp_c3_batch_n64_m1.json")
+    gens = bpa.Gens(ctx, bytes.fromhex(b["g_vec"]), bytes.fromhex(b["h_vec"]), bytes.fromhex(b["G"]), bytes.fromhex(b["H"]), window_bits)
+    return b, gens, bytearray(bytes.fromhex(b["proofs"])), bytes.fromhex(b["commitments"]), 292 + 66 * 6
+
+
+@pytest.mark.parametrize("count", [1, 3, 256])
+def test_rlc_all_valid_takes_the_combined_path(ctx, count):
+    b, gens, proofs, coms, plen = _c3(ctx)
+    try:
+        for seed in (b"\x00" * 32, bytes(range(32)), b"\xff" * 32):
+            got, fb = ctx.rangeproof_verify_batch_rlc(gens, 64, 1, bytes(proofs[:count * plen]), coms[:count * 64], seed)
+            assert got == [0] * count and not fb
+    finally:
+        gens.close()
+
+
+def test_rlc_with_invalid_proofs_gives_the_per_proof_verdicts(ctx):
+    """A batch holding invalid proofs fails the combined check and falls back: verdict bytes equal
+    bp_rangeproof_verify_batch's (the oracle's), whichever proofs were tampered and however."""
+    b, gens, proofs, coms, plen = _c3(ctx)
+    try:
+        cnt = b["count"]
+        for tampered in ([7], [0], [cnt - 1], list(range(3, cnt, 5))):
+            p = bytearray(proofs)
+            for i in tampered:
+                p[i * plen + 4 * 33 + 64 + 31] ^= 1  # tx bit
+            want = [3 if i in tampered else 0 for i in range(cnt)]
+            got, fb = ctx.rangeproof_verify_batch_rlc(gens, 64, 1, bytes(p), coms, b"seed" * 8)
+            assert fb and got == want
+            assert got == ctx.rangeproof_verify_batch(gens, 64, 1, bytes(p), coms)
+        # a single wrong commitment (valid point, wrong statement)
+        c = bytearray(coms)
+        c[64 * 5:64 * 6] = coms[64 * 6:64 * 7]
+        got, fb = ctx.rangeproof_verify_batch_rlc(gens, 64, 1, bytes(proofs), bytes(c), b"seed" * 8)
+        assert fb and got == [3 if i == 5 else 0 for i in range(cnt)]
+    finally:
+        gens.close()
+
+
+def test_rlc_malformed_proofs_are_left_out_of_the_combination(ctx):
+    """Undeserialisable proofs (bad point prefix, scalar >= q) get 255 and do not spoil the combined check."""
+    b, gens, proofs, coms, plen = _c3(ctx)
+    try:
+        cnt = 64
+        p = bytearray(proofs[:cnt * plen])
+        p[9 * plen] = 7  # A of proof 9: invalid SEC1 prefix
+        p[20 * plen + 4 * 33:20 * plen + 4 * 33 + 32] = b"\xff" * 32  # tau_x of proof 20 >= q
+        want = [255 if i in (9, 20) else 0 for i in range(cnt)]
+        got, fb = ctx.rangeproof_verify_batch_rlc(gens, 64, 1, bytes(p), coms[:cnt * 64], b"\x11" * 32)
+        assert got == want and not fb
+        assert ctx.rangeproof_verify_batch(gens, 64, 1, bytes(p), coms[:cnt * 64]) == want
+    finally:
+        gens.close()
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_rlc_small_cases_all_shapes(ctx, idx):
+    """n, m shapes of the golden cases (m > 1: several commitments per proof), valid proof repeated + tampered ones."""
+    case = bp_cases()[idx]
+    n, m = case["n"], case["m"]
+    gens = _gens(ctx, n, m, window_bits=8)
+    try:
+        good_p = bytes.fromhex(case["proof"])
+        good_c = b"".join(bytes.fromhex(c) for c in case["commitments"])
+        got, fb = ctx.rangeproof_verify_batch_rlc(gens, n, m, good_p * 5, good_c * 5, b"\x42" * 32)
+        assert got == [0] * 5 and not fb
+        proofs = [good_p] + [bytes.fromhex(t["proof"]) for t in case["tampered"]]
+        coms = [good_c] + [b"".join(bytes.fromhex(c) for c in t["commitments"]) for t in case["tampered"]]
+        want = [VERDICT_CODE[case["verdict"]]] + [VERDICT_CODE[t["verdict"]] for t in case["tampered"]]
+        got, fb = ctx.rangeproof_verify_batch_rlc(gens, n, m, b"".join(proofs), b"".join(coms), b"\x42" * 32)
+        assert got == want
+    finally:
+        gens.close()
