@@ -308,7 +308,15 @@ __global__ __launch_bounds__(64) void k_bpv_hash2(int k, int m, size_t nproofs, 
 #define CS_XINV(k) (3 + (k))           // k : x_j^-1
 #define CS_YINVP(k) (3 + 2 * (k))      // k : y^-(2^t)
 #define CS_ZPOW(k) (3 + 3 * (k))       // m : z^(2+j)
-#define CS_COUNT(k, m) (3 + 3 * (k) + (m))
+// split-index tables for k_bpv_vec: i = hi * 2^LO + lo with LO = k/2 low bits and k - LO high bits;
+// s_i = SLO[lo] * SHI[hi], s_i^-1 = s_{nm-1-i} = SLO[~lo] * SHI[~hi], y^-i = YLO[lo] * YHI[hi]
+#define CS_LOBITS(k) ((k) / 2)
+#define CS_HIBITS(k) ((k) - (k) / 2)
+#define CS_SLO(k, m) (3 + 3 * (k) + (m))
+#define CS_SHI(k, m) (CS_SLO(k, m) + (1 << CS_LOBITS(k)))
+#define CS_YLO(k, m) (CS_SHI(k, m) + (1 << CS_HIBITS(k)))
+#define CS_YHI(k, m) (CS_YLO(k, m) + (1 << CS_LOBITS(k)))
+#define CS_COUNT(k, m) (CS_YHI(k, m) + (1 << CS_HIBITS(k)))
 #define BPV_MAXK 16
 
 __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
@@ -414,6 +422,31 @@ __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ p
     cs[CS_Z] = z_m;
     cs[CS_A] = a_m;
     cs[CS_B] = b_m;
+    // split-index tables: one product per entry (flipping bit t of the index from x^-1 to x multiplies by x^2)
+    {
+        const int LO = CS_LOBITS(k), HI = CS_HIBITS(k);
+        fqm *slo = cs + CS_SLO(k, m), *shi = cs + CS_SHI(k, m), *ylo = cs + CS_YLO(k, m), *yhi = cs + CS_YHI(k, m);
+        fqm p = ONE;
+        for (int t = 0; t < LO; t++) p = fqm_mul(p, cs[CS_XINV(k) + (k - 1 - t)]);
+        slo[0] = p;
+        ylo[0] = ONE;
+        for (int j = 1; j < (1 << LO); j++) {
+            const int t = 31 - __builtin_clz((unsigned)j);  // top set bit
+            const fqm xm = cs[CS_XJ + (k - 1 - t)];
+            slo[j] = fqm_mul(slo[j - (1 << t)], fqm_mul(xm, xm));
+            ylo[j] = fqm_mul(ylo[j - (1 << t)], cs[CS_YINVP(k) + t]);
+        }
+        p = ONE;
+        for (int t = 0; t < HI; t++) p = fqm_mul(p, cs[CS_XINV(k) + (k - 1 - LO - t)]);
+        shi[0] = p;
+        yhi[0] = ONE;
+        for (int j = 1; j < (1 << HI); j++) {
+            const int t = 31 - __builtin_clz((unsigned)j);
+            const fqm xm = cs[CS_XJ + (k - 1 - LO - t)];
+            shi[j] = fqm_mul(shi[j - (1 << t)], fqm_mul(xm, xm));
+            yhi[j] = fqm_mul(yhi[j - (1 << t)], cs[CS_YINVP(k) + LO + t]);
+        }
+    }
 }
 
 // One lane per (proof, i): g_i : a s_i + z ; h_i : y^-i (b s_i^-1 - d_i) - z          :670-705
@@ -427,18 +460,12 @@ __global__ __launch_bounds__(256) void k_bpv_vec(int n_bits, int m, int k, size_
     int i = (int)(gid % nm);
     if (bad[pr]) return;
     const fqm* cs = cst + pr * CS_COUNT(k, m);
-    fqm s = fqm_one(), sinv = s, yip = s;
-    for (int t = 0; t < k; t++) {
-        fqm xm = cs[CS_XJ + (k - 1 - t)], xi = cs[CS_XINV(k) + (k - 1 - t)];
-        if ((i >> t) & 1) {
-            s = fqm_mul(s, xm);
-            sinv = fqm_mul(sinv, xi);
-            yip = fqm_mul(yip, cs[CS_YINVP(k) + t]);
-        } else {
-            s = fqm_mul(s, xi);
-            sinv = fqm_mul(sinv, xm);
-        }
-    }
+    const int LO = CS_LOBITS(k), lom = (1 << LO) - 1, him = (1 << CS_HIBITS(k)) - 1;
+    const int lo = i & lom, hi = i >> LO;
+    const fqm *slo = cs + CS_SLO(k, m), *shi = cs + CS_SHI(k, m);
+    fqm s = fqm_mul(slo[lo], shi[hi]);
+    fqm sinv = fqm_mul(slo[lom - lo], shi[him - hi]);
+    fqm yip = fqm_mul(cs[CS_YLO(k, m) + lo], cs[CS_YHI(k, m) + hi]);
     fqm z_m = cs[CS_Z];
     fqm gs = fqm_add(fqm_mul(cs[CS_A], s), z_m);
     fq two_r = fq_zero();
