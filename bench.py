@@ -54,6 +54,7 @@ def parse():
                          "prove = single-proof prove / verify latencies of BASELINE.json configs[0], [1], [3] (one GPU)")
     ap.add_argument("--msm-log2", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rlc-single", action="store_true", help="RLC side measurement with one context instead of two")
     ap.add_argument("--no-rlc", action="store_true", help="skip the random-linear-combination side measurement")
     ap.add_argument("--skip-check", action="store_true", help="timing experiments only: do not compare verdicts")
     ap.add_argument("--cpu-sample", type=int, default=1200, help="proofs verified by the CPU baseline")
@@ -363,17 +364,35 @@ def main():
         seed = bytes((7 * i + rank) & 255 for i in range(32))
         fb = ctx.rangeproof_verify_batch_rlc_device(gens, 64, 1, d_valid.data_ptr(), plen, d_coms.data_ptr(), P, seed, d_v2.data_ptr())
         assert not fb and not bool(d_v2.any().item()), "rlc: all-valid batch must pass the combined check"
+        # two contexts on two host threads (the library's threading model: one bp_ctx per thread, bp_gens shared):
+        # the latency-bound tail of one batch's MSM overlaps the other batch's decompression / accumulation
+        import threading
+        ctx_b = bpa.Context(local_rank)
+        d_v3 = torch.full((P,), 77, dtype=torch.uint8, device=dev)
+        ctx_b.rangeproof_verify_batch_rlc_device(gens, 64, 1, d_valid.data_ptr(), plen, d_coms.data_ptr(), P, seed, d_v3.data_ptr())
+        nthr = 1 if args.rlc_single else 2
+
+        def worker(c, dv, cnt):
+            for _ in range(cnt):
+                c.rangeproof_verify_batch_rlc_device(gens, 64, 1, d_valid.data_ptr(), plen, d_coms.data_ptr(), P, seed, dv.data_ptr())
+
+        share = [args.steps - args.steps // nthr * (nthr - 1)] + [args.steps // nthr] * (nthr - 1)
+        thr = [threading.Thread(target=worker, args=(c, dv, cnt)) for c, dv, cnt in zip((ctx, ctx_b), (d_v2, d_v3), share)]
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            ctx.rangeproof_verify_batch_rlc_device(gens, 64, 1, d_valid.data_ptr(), plen, d_coms.data_ptr(), P, seed, d_v2.data_ptr())
+        for t in thr:
+            t.start()
+        for t in thr:
+            t.join()
         barrier()
         dt_rlc = time.perf_counter() - t0
+        assert not bool(d_v2.any().item()) and not bool(d_v3.any().item())
+        ctx_b.close()
         if world > 1:
             t = torch.tensor([dt_rlc], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_rlc = float(t.item())
-        rlc = {"value": world * P * args.steps / dt_rlc, "unit": "proofs/s", "ms_per_step": dt_rlc / args.steps * 1e3,
+        rlc = {"value": world * P * args.steps / dt_rlc, "unit": "proofs/s", "ms_per_step": dt_rlc / args.steps * 1e3, "contexts_in_flight": nthr,
                "what": "bp_rangeproof_verify_batch_rlc_device on the same batch with no tampered proof: one fixed-base MSM over the "
                        "generators + one %d-point Pippenger MSM per step; a failing batch falls back to the per-proof path" % (17 * P)}
 
