@@ -37,7 +37,7 @@ __device__ __forceinline__ xyzz fb_block_sum(xyzz acc, xyzz* red, int tid) {
     return red[0];
 }
 
-__global__ __launch_bounds__(FB_T) void k_fb_acc(const affine_mem* __restrict__ table, int W, int NB, const int16_t* __restrict__ dig,
+__global__ __launch_bounds__(FB_T) void k_fb_acc(const affine_mem* __restrict__ table, int W, int NB, const tdig_t* __restrict__ dig,
                                                  const uint32_t* __restrict__ gidx, const uint32_t* __restrict__ toff,
                                                  const affine_mem* __restrict__ xpts, const uint8_t* __restrict__ xsc_be,
                                                  const uint32_t* __restrict__ xoff, int nblk, int nxblk, xyzz* __restrict__ vartab,
@@ -52,7 +52,6 @@ __global__ __launch_bounds__(FB_T) void k_fb_acc(const affine_mem* __restrict__ 
             const uint32_t t = t0 + (uint32_t)(it / W);
             const int w = (int)(it % W);
             int d = dig[(size_t)t * W + w];
-            if (d == -32768) d = 32768;  // c = 16: the digit +2^15 wraps in int16; -2^15 itself never occurs
             if (d != 0) {
                 affine e = affine_load(table[((size_t)gidx[t] * W + w) * NB + ((d < 0 ? -d : d) - 1)]);
                 if (d < 0) e.y = fp_neg(e.y);
@@ -87,7 +86,7 @@ __global__ __launch_bounds__(FB_T) void k_fb_final(const xyzz* __restrict__ part
 size_t fb_vartab_bytes(size_t njobs, int nxblk) { return njobs * (size_t)nxblk * FB_T * ECMUL_NT * sizeof(xyzz); }
 
 // nblk: blocks per job over the generator items (>= 1); nxblk: blocks per job over the extras (0 = none)
-hipError_t launch_fb_msm(size_t njobs, const affine_mem* table, int W, int NB, const int16_t* dig, const uint32_t* gidx, const uint32_t* toff,
+hipError_t launch_fb_msm(size_t njobs, const affine_mem* table, int W, int NB, const tdig_t* dig, const uint32_t* gidx, const uint32_t* toff,
                          const affine_mem* xpts, const uint8_t* xsc_be, const uint32_t* xoff, int nblk, int nxblk, xyzz* vartab, xyzz* partial,
                          uint8_t* out_be, hipStream_t st) {
     if (njobs == 0) return hipSuccess;

@@ -34,17 +34,26 @@ __global__ void k_xyzz_to_affine(const xyzz* __restrict__ in, affine_mem* __rest
     out[i] = affine_store(xyzz_to_affine(in[i]));
 }
 
-// tmp[idx*NB + d-1] = d * B_idx, d = 1..NB; one thread per idx = p*W + w.
-__global__ void k_gens_multiples(const affine_mem* __restrict__ basesA, size_t nidx, int NB, xyzz* __restrict__ tmp) {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// tmp[idx*NB + d-1] = d * B_idx, d = 1..NB; one thread per (idx = p*W + w, segment of NB/segs multiples):
+// a segment starts from (seg * NB/segs) * B by double-and-add, so wide windows (NB = 2^19) do not leave the
+// GPU on a handful of half-million-step serial chains.
+__global__ void k_gens_multiples(const affine_mem* __restrict__ basesA, size_t nidx, int NB, int segs, xyzz* __restrict__ tmp) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t idx = g / segs;
+    const int seg = (int)(g % segs);
     if (idx >= nidx) return;
     affine B = affine_load(basesA[idx]);
-    xyzz acc = xyzz_from_affine(B);
-    xyzz* dst = tmp + idx * (size_t)NB;
-    dst[0] = acc;
-    for (int d = 2; d <= NB; d++) {
+    const int S = NB / segs;
+    const uint32_t k0 = (uint32_t)seg * (uint32_t)S;
+    xyzz acc = xyzz_inf();
+    for (int b = 31; b >= 0; b--) {
+        acc = xyzz_dbl(acc);
+        if ((k0 >> b) & 1) xyzz_madd(acc, B);
+    }
+    xyzz* dst = tmp + idx * (size_t)NB + k0;
+    for (int d = 0; d < S; d++) {
         xyzz_madd(acc, B);
-        dst[d - 1] = acc;
+        dst[d] = acc;
     }
 }
 
@@ -85,7 +94,10 @@ hipError_t launch_xyzz_to_affine(const xyzz* in, affine_mem* out, size_t n, hipS
     return hipGetLastError();
 }
 hipError_t launch_gens_multiples(const affine_mem* basesA, size_t nidx, int NB, xyzz* tmp, hipStream_t st) {
-    hipLaunchKernelGGL(k_gens_multiples, dim3((unsigned)((nidx + 63) / 64)), dim3(64), 0, st, basesA, nidx, NB, tmp);
+    int segs = NB / 8192;  // chains of at most 8192 additions
+    if (segs < 1) segs = 1;
+    const size_t lanes = nidx * (size_t)segs;
+    hipLaunchKernelGGL(k_gens_multiples, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, basesA, nidx, NB, segs, tmp);
     return hipGetLastError();
 }
 hipError_t launch_gens_normalize(const xyzz* tmp, size_t n, affine_mem* table, hipStream_t st) {

@@ -9,6 +9,9 @@
 
 namespace bp {
 
+// signed window digit of a fixed-base table term (tables go up to 20-bit windows: |digit| <= 2^19)
+typedef int32_t tdig_t;
+
 // msm_kernels.hip
 size_t msm_slice_lds_bytes(int c, int M, int T);
 hipError_t launch_ingest_points(const uint8_t* in_be, affine_mem* out, size_t n, int* err, hipStream_t st);
@@ -50,7 +53,7 @@ hipError_t launch_bpv_decompress(const uint8_t* proofs, size_t proof_len, const 
 size_t bpv_chal_count(int k);
 size_t bpv_cst_count(int k, int m);
 hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
-                                      const affine_mem* gens, const affine_mem* table, int c, int W, int16_t* digF, fqm* scF, fq* varS, fq* chal,
+                                      const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fqm* scF, fq* varS, fq* chal,
                                       fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st);
 // rlc_kernels.hip: random-linear-combination batch verification (one MSM for the whole batch)
 hipError_t launch_rlc_weights(const uint8_t* seed32, size_t nproofs, const int* bad, fqm* rho, hipStream_t st);
@@ -59,19 +62,19 @@ size_t rlc_colsum_chunks(size_t nproofs);
 hipError_t launch_rlc_colsum(int np, size_t nproofs, const fqm* rho, const fqm* scF, const int* bad, fqm* part, uint8_t* out_be, hipStream_t st);
 hipError_t launch_rlc_verdicts(size_t nproofs, const uint8_t* result_be, const int* bad, uint8_t* verdicts, int* all_ok, hipStream_t st);
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
-                          const int16_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st);
+                          const tdig_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st);
 size_t bpv_msm_vartab_bytes(int tp, size_t nproofs);
 
 
 // msm_batch.hip
-hipError_t launch_mb_digits(const uint8_t* scalars_be, size_t total, int c, int W, int16_t* digits, hipStream_t st);
+hipError_t launch_mb_digits(const uint8_t* scalars_be, size_t total, int c, int W, tdig_t* digits, hipStream_t st);
 size_t mb_vartab_bytes(size_t njobs);
-hipError_t launch_mb_msm(size_t njobs, int np, const affine_mem* table, int c, int W, const int16_t* digF, const uint8_t* has_gen,
+hipError_t launch_mb_msm(size_t njobs, int np, const affine_mem* table, int c, int W, const tdig_t* digF, const uint8_t* has_gen,
                          const affine_mem* xpts, const uint8_t* xsc_be, const uint32_t* xoff, xyzz* vartab, xyzz* out, hipStream_t st);
 
 // fbmsm.hip: few jobs over the generator table, whole-chip parallel (prover / single-proof verifier)
 size_t fb_vartab_bytes(size_t njobs, int nxblk);
-hipError_t launch_fb_msm(size_t njobs, const affine_mem* table, int W, int NB, const int16_t* dig, const uint32_t* gidx, const uint32_t* toff,
+hipError_t launch_fb_msm(size_t njobs, const affine_mem* table, int W, int NB, const tdig_t* dig, const uint32_t* gidx, const uint32_t* toff,
                          const affine_mem* xpts, const uint8_t* xsc_be, const uint32_t* xoff, int nblk, int nxblk, xyzz* vartab, xyzz* partial,
                          uint8_t* out_be, hipStream_t st);
 

@@ -17,11 +17,11 @@
 
 namespace bp {
 
-__global__ void k_mb_digits(const uint8_t* __restrict__ scalars_be, size_t total, int c, int W, int16_t* __restrict__ digits) {
+__global__ void k_mb_digits(const uint8_t* __restrict__ scalars_be, size_t total, int c, int W, tdig_t* __restrict__ digits) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     fq k = fq_from_be_reduce(scalars_be + 32 * i);
-    int16_t* out = digits + i * (size_t)W;
+    tdig_t* out = digits + i * (size_t)W;
     uint32_t carry = 0;
     const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
     for (int w = 0; w < W; w++) {
@@ -42,13 +42,13 @@ __global__ void k_mb_digits(const uint8_t* __restrict__ scalars_be, size_t total
             d = (int)v;
             carry = 0;
         }
-        out[w] = (int16_t)d;
+        out[w] = (tdig_t)d;
     }
 }
 
 #define MB_TP 16
 __global__ __launch_bounds__(256, 2) void k_mb_msm(size_t njobs, int np, const affine_mem* __restrict__ table, int c, int W,
-                                                   const int16_t* __restrict__ digF, const uint8_t* __restrict__ has_gen,
+                                                   const tdig_t* __restrict__ digF, const uint8_t* __restrict__ has_gen,
                                                    const affine_mem* __restrict__ xpts, const uint8_t* __restrict__ xsc_be,
                                                    const uint32_t* __restrict__ xoff, xyzz* __restrict__ vartab, int8_t* __restrict__ vardig,
                                                    xyzz* __restrict__ out) {
@@ -60,10 +60,9 @@ __global__ __launch_bounds__(256, 2) void k_mb_msm(size_t njobs, int np, const a
     if (job < njobs) {
         if (has_gen[job]) {
             const int nfw = np * W;
-            const int16_t* dg = digF + job * (size_t)nfw;
+            const tdig_t* dg = digF + job * (size_t)nfw;
             for (int idx = lane; idx < nfw; idx += MB_TP) {
                 int d = dg[idx];
-                if (d == -32768) d = 32768;  // c = 16: the digit +2^15 wraps in int16; -2^15 itself never occurs
                 if (d != 0) {
                     affine e = affine_load(table[(size_t)idx * NB + ((d < 0 ? -d : d) - 1)]);
                     if (d < 0) e.y = fp_neg(e.y);
@@ -94,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void k_mb_msm(size_t njobs, int np, const a
     if (lane == 0 && job < njobs) out[job] = red[tid];
 }
 
-hipError_t launch_mb_digits(const uint8_t* scalars_be, size_t total, int c, int W, int16_t* digits, hipStream_t st) {
+hipError_t launch_mb_digits(const uint8_t* scalars_be, size_t total, int c, int W, tdig_t* digits, hipStream_t st) {
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(k_mb_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scalars_be, total, c, W, digits);
     return hipGetLastError();
@@ -103,7 +102,7 @@ size_t mb_vartab_bytes(size_t njobs) {
     size_t blocks = (njobs + (256 / MB_TP) - 1) / (256 / MB_TP);
     return blocks * 256 * (ECMUL_NT * sizeof(xyzz) + ECMUL_DIGB);
 }
-hipError_t launch_mb_msm(size_t njobs, int np, const affine_mem* table, int c, int W, const int16_t* digF, const uint8_t* has_gen,
+hipError_t launch_mb_msm(size_t njobs, int np, const affine_mem* table, int c, int W, const tdig_t* digF, const uint8_t* has_gen,
                          const affine_mem* xpts, const uint8_t* xsc_be, const uint32_t* xoff, xyzz* vartab, xyzz* out, hipStream_t st) {
     unsigned blocks = (unsigned)((njobs + (256 / MB_TP) - 1) / (256 / MB_TP));
     int8_t* vardig = reinterpret_cast<int8_t*>(vartab + (size_t)blocks * 256 * ECMUL_NT);

@@ -199,7 +199,7 @@ int fbmsm(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs, Pt* out
     const size_t out_bytes = nj * 64 + sizeof(int);
     RC(pin_reserve(ctx, up_bytes + out_bytes));
     RC(ctx->fb[0].reserve(o_xpts + nxa * sizeof(affine_mem)));
-    RC(ctx->fb[1].reserve(nta * (size_t)W * sizeof(int16_t)));
+    RC(ctx->fb[1].reserve(nta * (size_t)W * sizeof(tdig_t)));
     RC(ctx->fb[2].reserve(nj * (size_t)nparts * sizeof(xyzz) + out_bytes));
     if (nxblk) RC(ctx->vartab.reserve(fb_vartab_bytes(nj, nxblk)));
     uint8_t* hp = (uint8_t*)ctx->h_pin;
@@ -234,8 +234,8 @@ int fbmsm(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs, Pt* out
     HIPCHK(hipMemsetAsync(d_err, 0, sizeof(int), st), "memset");
     HIPCHK(hipMemcpyAsync(d, hp, up_bytes, hipMemcpyHostToDevice, st), "h2d");
     if (nx) HIPCHK(launch_ingest_points(d + o_xbe, d_xpts, nx, d_err, st), "ingest");
-    if (nt) HIPCHK(launch_mb_digits(d + o_sc, nt, g->c, W, (int16_t*)ctx->fb[1].p, st), "digits");
-    HIPCHK(launch_fb_msm(nj, g->d_table, W, NB, (const int16_t*)ctx->fb[1].p, (const uint32_t*)(d + o_gidx), (const uint32_t*)(d + o_toff), d_xpts,
+    if (nt) HIPCHK(launch_mb_digits(d + o_sc, nt, g->c, W, (tdig_t*)ctx->fb[1].p, st), "digits");
+    HIPCHK(launch_fb_msm(nj, g->d_table, W, NB, (const tdig_t*)ctx->fb[1].p, (const uint32_t*)(d + o_gidx), (const uint32_t*)(d + o_toff), d_xpts,
                          d + o_xsc, (const uint32_t*)(d + o_xoff), nblk, nxblk, (xyzz*)ctx->vartab.p, d_partial, d_out, st),
            "fb_msm");
     uint8_t* h_out = hp + up_bytes;

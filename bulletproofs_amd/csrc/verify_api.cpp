@@ -20,14 +20,20 @@ using namespace bp;
         }                          \
     } while (0)
 
+#define BP_MAX_TABLE_WINDOW 20
 static int pick_table_window(int np) {
-    // largest c in [4, 16] whose table (np * W * 2^(c-1) * 64 B) stays <= 6 GiB of the 288 GB HBM
-    // (n=64 m=1: c = 16, 4.3 GiB; every extra window bit removes ~6 % of the verifier's table additions;
-    // the build needs 2.25x that as XYZZ scratch, freed afterwards)
+    // widest c in [4, 20] whose table (np * W * 2^(c-1) * 64 B) stays <= 64 GiB of the 288 GB HBM and whose build
+    // (table + 2.25x as XYZZ scratch, freed afterwards) fits in 80 % of the memory that is free right now.
+    // n=64 m=1: c = 20, 52.8 GiB, 13 gathers per generator term (c = 16: 4.3 GiB, 17 gathers); measured with a
+    // 68 GiB table (scratch/bigtable_test.py): the time per table addition is within 2 % of a 5 GiB table's -
+    // 64-byte gathers do not care how large the table is, so HBM capacity buys additions directly.
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
     int best = 4;
-    for (int c = 4; c <= 16; c++) {
+    for (int c = 4; c <= BP_MAX_TABLE_WINDOW; c++) {
         size_t bytes = (size_t)np * (256 / c + 1) * ((size_t)1 << (c - 1)) * 64;
-        if (bytes <= ((size_t)6 << 30)) best = c;
+        double need = (double)bytes * 3.25 + (double)((size_t)2 << 30);
+        if (bytes <= ((size_t)64 << 30) && need <= 0.8 * (double)free_b) best = c;
     }
     return best;
 }
@@ -43,7 +49,7 @@ int bp_gens_create(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t
     hipStream_t st = ctx->stream;
     int np = (int)(2 * nm + 2);
     int c = window_bits ? window_bits : pick_table_window(np);
-    if (c < 2 || c > 16) return BP_EINVAL;
+    if (c < 2 || c > BP_MAX_TABLE_WINDOW) return BP_EINVAL;
     int W = 256 / c + 1, NB = 1 << (c - 1);
     bp_gens* g = new bp_gens();
     g->device = ctx->device;
@@ -220,7 +226,7 @@ static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bi
     DevBuf &b_pts = ctx->scratch[0], &b_bad = ctx->scratch[1], &b_dig = ctx->scratch[2], &b_var = ctx->scratch[3], &b_s = ctx->scratch[4];
     if ((rc = b_pts.reserve(nproofs * NPT * sizeof(affine_mem))) != BP_OK) return rc;
     if ((rc = b_bad.reserve(nproofs * sizeof(int))) != BP_OK) return rc;
-    if ((rc = b_dig.reserve(nproofs * (size_t)gens->np * gens->W * sizeof(int16_t))) != BP_OK) return rc;
+    if ((rc = b_dig.reserve(nproofs * (size_t)gens->np * gens->W * sizeof(tdig_t))) != BP_OK) return rc;
     if ((rc = b_var.reserve(nproofs * NV * sizeof(fq))) != BP_OK) return rc;
     if ((rc = b_s.reserve(nproofs * (bpv_chal_count(k) + bpv_cst_count(k, m)) * sizeof(fq))) != BP_OK) return rc;
     if ((rc = ctx->fixres.reserve(nproofs * 2 * (sizeof(xyzz) + sizeof(affine_mem)))) != BP_OK) return rc;
@@ -238,7 +244,7 @@ static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bi
            "bpv_decompress");
     prof_mark(ctx, 1);
     HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
-                                      gens->d_table, gens->c, gens->W, (int16_t*)b_dig.p, nullptr, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
+                                      gens->d_table, gens->c, gens->W, (tdig_t*)b_dig.p, nullptr, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
                                       (int*)b_bad.p, st),
            "bpv_scalars");
     prof_mark(ctx, 2);
@@ -247,7 +253,7 @@ static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bi
     int tp = ctx->verify_lanes;
     if (tp != 4 && tp != 8 && tp != 16 && tp != 32 && tp != 64) tp = nproofs >= 32768 ? 4 : (nproofs >= 12288 ? 8 : 16);
     if ((rc = ctx->vartab.reserve(bpv_msm_vartab_bytes(tp, nproofs))) != BP_OK) return rc;
-    HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_table, gens->c, gens->W, (const int16_t*)b_dig.p,
+    HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_table, gens->c, gens->W, (const tdig_t*)b_dig.p,
                           (const fq*)b_var.p, (xyzz*)ctx->vartab.p, (const int*)b_bad.p, (uint8_t*)d_verdicts, st),
            "bpv_msm");
     prof_mark(ctx, 3);
@@ -295,7 +301,7 @@ int bp_rangeproof_verify_batch_rlc_device(bp_ctx* ctx, const bp_gens* gens, int 
                  o_toff = o_gidx + (size_t)np * 4, o_xoff = o_toff + 8, o_res = (o_xoff + 8 + 63) / 64 * 64, o_init = o_res + 64,
                  o_ok = o_init + sizeof(affine_mem), misc_bytes = o_ok + 64;
     if ((rc = b_misc.reserve(misc_bytes)) != BP_OK) return rc;
-    if ((rc = ctx->fb[1].reserve((size_t)np * W * sizeof(int16_t))) != BP_OK) return rc;
+    if ((rc = ctx->fb[1].reserve((size_t)np * W * sizeof(tdig_t))) != BP_OK) return rc;
     int nblk = (int)(((size_t)np * W + 255) / 256);
     if (nblk > 128) nblk = 128;
     if ((rc = ctx->fb[2].reserve((size_t)nblk * sizeof(xyzz))) != BP_OK) return rc;
@@ -325,8 +331,8 @@ int bp_rangeproof_verify_batch_rlc_device(bp_ctx* ctx, const bp_gens* gens, int 
     HIPCHK(launch_rlc_colsum(np, nproofs, (const fqm*)b_rho.p, (const fqm*)b_scF.p, (const int*)b_bad.p, (fqm*)(misc + o_part), misc + o_fbe, st),
            "rlc_colsum");
     // the 2nm+2 generator terms: one fixed-base MSM from the table; its value is the init of the big MSM
-    HIPCHK(launch_mb_digits(misc + o_fbe, (size_t)np, gens->c, W, (int16_t*)ctx->fb[1].p, st), "digits");
-    HIPCHK(launch_fb_msm(1, gens->d_table, W, gens->NB, (const int16_t*)ctx->fb[1].p, (const uint32_t*)(misc + o_gidx),
+    HIPCHK(launch_mb_digits(misc + o_fbe, (size_t)np, gens->c, W, (tdig_t*)ctx->fb[1].p, st), "digits");
+    HIPCHK(launch_fb_msm(1, gens->d_table, W, gens->NB, (const tdig_t*)ctx->fb[1].p, (const uint32_t*)(misc + o_gidx),
                          (const uint32_t*)(misc + o_toff), nullptr, nullptr, (const uint32_t*)(misc + o_xoff), nblk, 0, nullptr,
                          (xyzz*)ctx->fb[2].p, misc + o_res, st),
            "fb_msm");
@@ -379,7 +385,7 @@ int bp_msm_batch(bp_ctx* ctx, const bp_gens* gens, const bp_msm_job* jobs, size_
     DevBuf &b_gsc = ctx->scratch[0], &b_dig = ctx->scratch[2], &b_x = ctx->scratch[3], &b_misc = ctx->scratch[4], &b_out = ctx->scratch[5];
     const size_t nxa = nx ? nx : 1;
     if ((rc = b_gsc.reserve(gsc.size())) != BP_OK) return rc;
-    if ((rc = b_dig.reserve(njobs * (size_t)np * gens->W * sizeof(int16_t))) != BP_OK) return rc;
+    if ((rc = b_dig.reserve(njobs * (size_t)np * gens->W * sizeof(tdig_t))) != BP_OK) return rc;
     if ((rc = b_x.reserve(nxa * (64 + 32 + sizeof(affine_mem)))) != BP_OK) return rc;
     if ((rc = b_misc.reserve((njobs + 1) * 4 + njobs + 16)) != BP_OK) return rc;
     if ((rc = b_out.reserve(njobs * (sizeof(xyzz) + sizeof(affine_mem) + 64))) != BP_OK) return rc;
@@ -399,8 +405,8 @@ int bp_msm_batch(bp_ctx* ctx, const bp_gens* gens, const bp_msm_job* jobs, size_
     HIPCHK(hipMemcpyAsync(d_xoff, xoff.data(), (njobs + 1) * 4, hipMemcpyHostToDevice, st), "memcpy offsets");
     HIPCHK(hipMemcpyAsync(d_has, has.data(), njobs, hipMemcpyHostToDevice, st), "memcpy flags");
     HIPCHK(launch_ingest_points(d_xbe, d_xpts, nx, ctx->d_err, st), "ingest");
-    HIPCHK(launch_mb_digits((const uint8_t*)b_gsc.p, njobs * (size_t)np, gens->c, gens->W, (int16_t*)b_dig.p, st), "mb_digits");
-    HIPCHK(launch_mb_msm(njobs, np, gens->d_table, gens->c, gens->W, (const int16_t*)b_dig.p, d_has, d_xpts, d_xsc, d_xoff, (xyzz*)ctx->vartab.p,
+    HIPCHK(launch_mb_digits((const uint8_t*)b_gsc.p, njobs * (size_t)np, gens->c, gens->W, (tdig_t*)b_dig.p, st), "mb_digits");
+    HIPCHK(launch_mb_msm(njobs, np, gens->d_table, gens->c, gens->W, (const tdig_t*)b_dig.p, d_has, d_xpts, d_xsc, d_xoff, (xyzz*)ctx->vartab.p,
                          d_res, st),
            "mb_msm");
     HIPCHK(launch_xyzz_to_affine(d_res, d_aff, njobs, st), "normalize");

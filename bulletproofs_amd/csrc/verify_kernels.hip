@@ -65,7 +65,7 @@ __global__ void k_bpv_decompress(const uint8_t* __restrict__ proofs, size_t proo
 // lane: the fewer lanes a proof has, the fewer chains it pays for); 256-thread workgroups.
 template <int TP, int PPL>
 __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int m, int k, size_t nproofs, const affine_mem* __restrict__ pts,
-                                                 const affine_mem* __restrict__ table, int c, int W, const int16_t* __restrict__ digF,
+                                                 const affine_mem* __restrict__ table, int c, int W, const tdig_t* __restrict__ digF,
                                                  const fq* __restrict__ varS, xyzz* __restrict__ vartab, int8_t* __restrict__ vardig,
                                                  const int* __restrict__ bad, uint8_t* __restrict__ verdicts, int dbg_skip) {
     __shared__ xyzz red[256];
@@ -80,10 +80,9 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
     xyzz acc = xyzz_inf();
     if (active) {
         const int nfw = (2 * nm + 2) * W;
-        const int16_t* dg = digF + pr * (size_t)nfw;
+        const tdig_t* dg = digF + pr * (size_t)nfw;
         for (int idx = lane; idx < ((dbg_skip & 1) ? 0 : nfw); idx += TP) {
             int d = dg[idx];
-            if (d == -32768) d = 32768;  // c = 16: the digit +2^15 wraps in int16; -2^15 itself never occurs
             if (d != 0) {
                 affine e = affine_load(table[(size_t)idx * NB + ((d < 0 ? -d : d) - 1)]);
                 if (d < 0) e.y = fp_neg(e.y);
@@ -149,7 +148,7 @@ size_t bpv_msm_vartab_bytes(int tp, size_t nproofs) {
     return blocks * 256 * bpv_ppl(tp) * (ECMUL_NT * sizeof(xyzz) + ECMUL_DIGB);
 }
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
-                          const int16_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st) {
+                          const tdig_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st) {
     unsigned blocks = (unsigned)((nproofs + (256 / tp) - 1) / (256 / tp));
     const char* e = getenv("BP_DEBUG_SKIP");  // timing experiments only: 1 = skip fixed part, 2 = skip variable part
     int dbg = e ? atoi(e) : 0;

@@ -205,9 +205,9 @@ __device__ __forceinline__ int window_digit(const fq& kk, int c, int w, uint32_t
     return (int)v;
 }
 
-__device__ __forceinline__ void store_digits(const fq& kk, int c, int W, int16_t* __restrict__ out) {
+__device__ __forceinline__ void store_digits(const fq& kk, int c, int W, tdig_t* __restrict__ out) {
     uint32_t carry = 0;
-    for (int w = 0; w < W; w++) out[w] = (int16_t)window_digit(kk, c, w, carry);
+    for (int w = 0; w < W; w++) out[w] = (tdig_t)window_digit(kk, c, w, carry);
 }
 
 // y*G and x_u*G per proof: table gathers + mixed adds.  FM_SUB lanes per multiplication (windows
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64) void k_bpv_hash2(int k, int m, size_t nproofs, 
 #define BPV_MAXK 16
 
 __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
-                                                   const fq* __restrict__ chal, int c, int W, int16_t* __restrict__ digF, fqm* __restrict__ scF,
+                                                   const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF, fqm* __restrict__ scF,
                                                    fq* __restrict__ varS, fqm* __restrict__ cst, int* __restrict__ bad) {
     size_t pr = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (pr >= nproofs || bad[pr]) return;
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ p
         scF[pr * (size_t)(2 * nm + 2) + 2 * nm] = sG;
         scF[pr * (size_t)(2 * nm + 2) + 2 * nm + 1] = sH;
     } else {
-        int16_t* dg = digF + pr * (size_t)(2 * nm + 2) * W;
+        tdig_t* dg = digF + pr * (size_t)(2 * nm + 2) * W;
         store_digits(fqm_to_fq(sG), c, W, dg + (size_t)(2 * nm) * W);
         store_digits(fqm_to_fq(sH), c, W, dg + (size_t)(2 * nm + 1) * W);
     }
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ p
 // One lane per (proof, i): g_i : a s_i + z ; h_i : y^-i (b s_i^-1 - d_i) - z          :670-705
 // s_i = prod_t (bit_t(i) ? x_{k-1-t} : x_{k-1-t}^-1), s_i^-1 = s_{nm-1-i}; d_i = z^(2+i/n) 2^(i mod n).
 __global__ __launch_bounds__(256) void k_bpv_vec(int n_bits, int m, int k, size_t nproofs, const fqm* __restrict__ cst, int c, int W,
-                                                 int16_t* __restrict__ digF, fqm* __restrict__ scF, const int* __restrict__ bad) {
+                                                 tdig_t* __restrict__ digF, fqm* __restrict__ scF, const int* __restrict__ bad) {
     const int nm = n_bits * m;
     size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= nproofs * (size_t)nm) return;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void k_bpv_vec(int n_bits, int m, int k, size_
         scF[pr * (size_t)(2 * nm + 2) + nm + i] = hs;
         return;
     }
-    int16_t* dg = digF + pr * (size_t)(2 * nm + 2) * W;
+    tdig_t* dg = digF + pr * (size_t)(2 * nm + 2) * W;
     store_digits(fqm_to_fq(gs), c, W, dg + (size_t)i * W);
     store_digits(fqm_to_fq(hs), c, W, dg + (size_t)(nm + i) * W);
 }
@@ -489,7 +489,7 @@ size_t bpv_chal_count(int k) { return CH_COUNT(k); }
 size_t bpv_cst_count(int k, int m) { return ((size_t)CS_COUNT(k, m) * sizeof(fqm) + sizeof(fq) - 1) / sizeof(fq); }
 
 hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
-                                      const affine_mem* gens, const affine_mem* table, int c, int W, int16_t* digF, fqm* scF, fq* varS, fq* chal,
+                                      const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fqm* scF, fq* varS, fq* chal,
                                       fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st) {
     const int nm = n_bits * m;
     hipLaunchKernelGGL(k_bpv_hash1, dim3((unsigned)((nproofs * 4 + 63) / 64)), dim3(64), 0, st, proofs, proof_len, k, m, nm, nproofs, pts, gens,

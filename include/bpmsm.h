@@ -97,7 +97,8 @@ void bp_proto_set_path(bp_ctx* ctx, int path);
 /* bp_gens — the shared generators g_vec[nm], h_vec[nm], G, H that the reference passes to every
  * prove/verify call as slices (range_proof.rs:46-49, 267-270, 539-542; StatementRP,
  * range_proof_wip.rs:39-45).  Uploaded once and expanded into a fixed-base window table in HBM
- * (window_bits = 0 picks the widest window whose table stays <= 6 GiB, at most 16 bits); immutable afterwards.
+ * (window_bits = 0 picks the widest window, at most 20 bits, whose table stays <= 64 GiB and whose build fits in the
+ * free HBM: n=64 m=1 -> 20 bits, 52.8 GiB; pass window_bits explicitly, 2..20, to trade memory for speed); immutable afterwards.
  * Infinity is not a valid generator (BP_EPOINT). */
 int bp_gens_create(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t nm, const uint8_t G_xy[64], const uint8_t H_xy[64],
                    int window_bits, bp_gens** out);
