@@ -83,11 +83,18 @@ BP_HD xyzz ec_mul_glv(const affine& P, const fq& k, xyzz* tab) {
 // 128 doublings shared by all of them (each extra point costs only its 66 window additions).  Used by
 // the batched verifier when a lane owns more than one proof-specific point.
 //   loadP(j) -> affine, loadK(j) -> fq   for j < cnt <= PPL
-//   tab: PPL * ECMUL_NT lane-private XYZZ entries, dig: PPL * ECMUL_DIGB lane-private bytes.
+//   tab: PPL * ECMUL_SLOTS lane-private XYZZ-sized slots, dig: PPL * ECMUL_DIGB lane-private bytes.
 // The doubling chain runs through Jacobian coordinates (xyzz_dbl_n: 2M + 5S per doubling).
-#define ECMUL_DIGB 72  // signed digits of k1 at [0, 33), of k2 at [36, 69)
+// The multiples 2P..8P of all the lane's points are brought to AFFINE form with ONE inversion (Montgomery's
+// trick over up to 7 * PPL values of ZZZ; prefix products in the two spare slots of every point), so each of
+// the ~62 window additions per point is a mixed addition (8M + 2S) instead of a full one (12M + 2S):
+// 7 multiplications per entry + 270 for the inversion buy ~250 per point.
+#define ECMUL_DIGB 72   // signed digits of k1 at [0, 33), of k2 at [36, 69)
+#define ECMUL_SLOTS 10  // per point: 8 table entries + 2 slots (8 field elements) of prefix products
 template <int PPL, class LoadP, class LoadK>
 BP_HD xyzz ec_mul_glv_multi(LoadP loadP, LoadK loadK, int cnt, xyzz* tab, int8_t* dig) {
+    uint32_t valid = 0;
+    fp run = fp_one();
     for (int j = 0; j < cnt; j++) {
         affine P = loadP(j);
         int8_t* dj = dig + j * ECMUL_DIGB;
@@ -95,14 +102,19 @@ BP_HD xyzz ec_mul_glv_multi(LoadP loadP, LoadK loadK, int cnt, xyzz* tab, int8_t
             for (int w = 0; w < ECMUL_DIGB; w++) dj[w] = 0;
             continue;
         }
-        xyzz* tj = tab + j * ECMUL_NT;
-        xyzz t = xyzz_from_affine(P);
-        tj[0] = t;
-        t = xyzz_dbl_affine(P);
+        valid |= 1u << j;
+        xyzz* tj = tab + j * ECMUL_SLOTS;
+        fp* pref = reinterpret_cast<fp*>(tj + ECMUL_NT);
+        *reinterpret_cast<affine*>(&tj[0]) = P;
+        xyzz t = xyzz_dbl_affine(P);
         tj[1] = t;
+        pref[1] = run;
+        run = fp_mul(run, t.ZZZ);
         for (int i = 2; i < ECMUL_NT; i++) {
             xyzz_madd(t, P);
             tj[i] = t;
+            pref[i] = run;
+            run = fp_mul(run, t.ZZZ);
         }
         fq k1, k2;
         bool n1, n2;
@@ -114,25 +126,43 @@ BP_HD xyzz ec_mul_glv_multi(LoadP loadP, LoadK loadK, int cnt, xyzz* tab, int8_t
             dj[36 + w] = (int8_t)(n2 ? -d2 : d2);
         }
     }
+    if (valid) {
+        fp inv = fp_inv(run);
+        for (int j = cnt - 1; j >= 0; j--) {
+            if (!((valid >> j) & 1)) continue;
+            xyzz* tj = tab + j * ECMUL_SLOTS;
+            const fp* pref = reinterpret_cast<const fp*>(tj + ECMUL_NT);
+            for (int i = ECMUL_NT - 1; i >= 1; i--) {
+                xyzz e = tj[i];
+                fp zi3 = fp_mul(inv, pref[i]);  // 1 / ZZZ_i
+                inv = fp_mul(inv, e.ZZZ);
+                fp zi = fp_mul(e.ZZ, zi3);      // ZZ / ZZZ = 1 / Z
+                affine a;
+                a.x = fp_mul(e.X, fp_sqr(zi));
+                a.y = fp_mul(e.Y, zi3);
+                *reinterpret_cast<affine*>(&tj[i]) = a;
+            }
+        }
+    }
     const fp beta = fp_beta();
     xyzz acc = xyzz_inf();
     for (int w = ECMUL_WINS - 1; w >= 0; w--) {
         if (w != ECMUL_WINS - 1) acc = xyzz_dbl_n(acc, 4);
         for (int j = 0; j < cnt; j++) {
             const int8_t* dj = dig + j * ECMUL_DIGB;
-            const xyzz* tj = tab + j * ECMUL_NT;
+            const xyzz* tj = tab + j * ECMUL_SLOTS;
             int d1 = dj[w];
             if (d1 != 0) {
-                xyzz e = tj[(d1 < 0 ? -d1 : d1) - 1];
-                if (d1 < 0) e.Y = fp_neg(e.Y);
-                xyzz_add(acc, e);
+                affine e = *reinterpret_cast<const affine*>(&tj[(d1 < 0 ? -d1 : d1) - 1]);
+                if (d1 < 0) e.y = fp_neg(e.y);
+                xyzz_madd(acc, e);
             }
             int d2 = dj[36 + w];
             if (d2 != 0) {
-                xyzz e = tj[(d2 < 0 ? -d2 : d2) - 1];
-                e.X = fp_mul(e.X, beta);
-                if (d2 < 0) e.Y = fp_neg(e.Y);
-                xyzz_add(acc, e);
+                affine e = *reinterpret_cast<const affine*>(&tj[(d2 < 0 ? -d2 : d2) - 1]);
+                e.x = fp_mul(e.x, beta);
+                if (d2 < 0) e.y = fp_neg(e.y);
+                xyzz_madd(acc, e);
             }
         }
     }

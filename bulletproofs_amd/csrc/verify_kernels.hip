@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
         const affine_mem* P = pts + pr * NPT;
         const fq* vs = varS + pr * (size_t)NV;
         const size_t gl = (size_t)blockIdx.x * 256 + tid;
-        xyzz* tab = vartab + gl * (PPL * ECMUL_NT);
+        xyzz* tab = vartab + gl * (PPL * ECMUL_SLOTS);
         int8_t* dig = vardig + gl * (PPL * ECMUL_DIGB);
         for (int v0 = lane; v0 < ((dbg_skip & 2) ? 0 : NV); v0 += TP * PPL) {
             int cnt = (NV - v0 + TP - 1) / TP;
@@ -142,21 +142,23 @@ hipError_t launch_bpv_decompress(const uint8_t* proofs, size_t proof_len, const 
     return hipGetLastError();
 }
 // lanes per proof -> proof-specific points per lane and pass
-static int bpv_ppl(int tp) { return tp == 4 ? 4 : (tp == 8 ? 2 : 1); }
+static int bpv_ppl(int tp) { return tp == 2 ? 8 : (tp == 4 ? 4 : (tp == 8 ? 2 : 1)); }
 size_t bpv_msm_vartab_bytes(int tp, size_t nproofs) {
     size_t blocks = (nproofs + (256 / tp) - 1) / (256 / tp);
-    return blocks * 256 * bpv_ppl(tp) * (ECMUL_NT * sizeof(xyzz) + ECMUL_DIGB);
+    return blocks * 256 * bpv_ppl(tp) * (ECMUL_SLOTS * sizeof(xyzz) + ECMUL_DIGB);
 }
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
                           const tdig_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st) {
     unsigned blocks = (unsigned)((nproofs + (256 / tp) - 1) / (256 / tp));
     const char* e = getenv("BP_DEBUG_SKIP");  // timing experiments only: 1 = skip fixed part, 2 = skip variable part
     int dbg = e ? atoi(e) : 0;
-    int8_t* vardig = reinterpret_cast<int8_t*>(vartab + (size_t)blocks * 256 * bpv_ppl(tp) * ECMUL_NT);
+    int8_t* vardig = reinterpret_cast<int8_t*>(vartab + (size_t)blocks * 256 * bpv_ppl(tp) * ECMUL_SLOTS);
 #define BPV_LAUNCH(TP, PPL)                                                                                                                  \
     hipLaunchKernelGGL((k_bpv_msm<TP, PPL>), dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, vardig, \
                        bad, verdicts, dbg)
-    if (tp == 4)
+    if (tp == 2)
+        BPV_LAUNCH(2, 8);
+    else if (tp == 4)
         BPV_LAUNCH(4, 4);
     else if (tp == 8)
         BPV_LAUNCH(8, 2);
