@@ -32,13 +32,14 @@ MAD32_PER_PROOF_TOTAL = 6.60e6      # + the two fixed-base multiplications y*G, 
 # v_mad_u64_u32 sustains 31.2e12 lane-results/s at 8 waves/SIMD (SURVEY's assumed quarter-rate
 # figure was 9.83e12; the measured one is the denominator used here).
 PEAK_MAD32_PER_S = 31.2e12
-# HBM-side traffic of one k_bpv_msm launch at the default configuration (65536 proofs, auto lanes and table
-# window), from the separate --pmc passes in profiles/r01_pmc_read.csv / r01_pmc_write.csv:
-# TCC_EA0_RDREQ 157.93e6 x 64 B + TCC_EA0_WRREQ 25.62e6 x 64 B.  The reads are 64-byte gathers (table
-# entries), not the 16-B/lane streaming pattern the guide's x2 correction was calibrated on: RDREQ x 64 B
-# already equals the algorithmic gather bytes (2210 table entries x 64 B = 141 KB per proof + digits), so
-# no doubling is applied.  11.7 GB in 16.3 ms = 0.72 TB/s, 9 % of HBM peak: the kernel is VALU-bound.
-PMC_TRAFFIC_BYTES_DEFAULT = 157.93e6 * 64 + 25.62e6 * 64
+# HBM-side traffic of one k_bpv_msm launch at the default configuration (65536 proofs, auto lanes, 20-bit table
+# windows), from the separate --pmc passes in profiles/r01_pmc_read.csv / r01_pmc_write.csv:
+# TCC_EA0_RDREQ 143.93e6 x 64 B (64-byte gathers of table entries and lane-private window tables, not the
+# 16-B/lane streaming pattern the guide's x2 correction was calibrated on: RDREQ x 64 B already matches the
+# algorithmic gather bytes, 1690 table entries x 64 B per proof + the ~1000 window-table reads, so no doubling)
+# + TCC_EA0_WRREQ 36.79e6 x 64 B + 19.75e6 x 32 B (the lane-private window tables).  12.2 GB in 13.9 ms =
+# 0.88 TB/s, 11 % of the HBM peak: the kernel is VALU-bound.
+PMC_TRAFFIC_BYTES_DEFAULT = 143.93e6 * 64 + 36.79e6 * 64 + 19.75e6 * 32
 
 
 def parse():
