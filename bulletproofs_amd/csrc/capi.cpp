@@ -115,6 +115,7 @@ SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
     // chunk of points per histogram workgroup: ~512 workgroups in flight, 4096..65536 points each
     size_t ch = 4096;
     while (ch < 65536 && ((n2 + ch - 1) / ch) * (size_t)pl.W > 512) ch *= 2;
+    if (const char* e = getenv("BP_MSM_CH")) ch = (size_t)atol(e) >= 1024 ? (size_t)atol(e) : ch;
     pl.CH = (int)ch;
     pl.nchunks = (int)((n2 + ch - 1) / ch);
     if (pl.nchunks < 1) pl.nchunks = 1;
@@ -131,6 +132,33 @@ SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
     pl.lo_bits = c / 2;  // LO = 2^lo_bits, HI = NB / LO; LO + HI <= 256 for c <= 15
     if (pl.lo_bits > c - 1) pl.lo_bits = c - 1;
     return pl;
+}
+
+// Window groups of the pipelined sorted path (top-down).  Measured at 2^20 / 2^22 points (gpurun_out sweeps,
+// DESIGN.md section 5): two groups are the optimum - an accumulation launch needs >= 4 windows (4 waves per SIMD)
+// to run at full rate, so finer pipelines lose more in the accumulation than the shorter exposed tail returns.
+// BP_MSM_GROUPS="3,3,2,1" overrides (tuning).
+static int plan_window_groups(int W, int* gsz) {
+    int ng = 0;
+    if (const char* e = getenv("BP_MSM_GROUPS")) {
+        int left = W;
+        const char* p = e;
+        while (*p && left > 0 && ng < SortedStreams::kMaxGroups) {
+            int v = atoi(p);
+            if (v <= 0) break;
+            if (v > left || ng == SortedStreams::kMaxGroups - 1) v = left;
+            gsz[ng++] = v;
+            left -= v;
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+        if (left > 0 && ng > 0) gsz[ng - 1] += left;
+        if (ng > 0) return ng;
+    }
+    if (W < 4) return 0;
+    gsz[0] = W - W / 2;
+    gsz[1] = W / 2;
+    return 2;
 }
 
 #define HIPCHK(expr, where)              \
@@ -187,7 +215,7 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
         const size_t nout = ((size_t)1 << pl.lo_bits) + (NB >> pl.lo_bits);
         if ((rc = ctx->digits.reserve((size_t)W * pl.npad * sizeof(int16_t))) != BP_OK) return rc;
         if ((rc = ctx->srt[0].reserve((size_t)W * pl.nchunks * NB * 4)) != BP_OK) return rc;
-        if ((rc = ctx->srt[1].reserve((size_t)W * (NB + 1) * 4 + 2 * ((size_t)W * NB + 1) * 4)) != BP_OK) return rc;
+        if ((rc = ctx->srt[1].reserve((size_t)W * (NB + 1) * 4)) != BP_OK) return rc;
         if ((rc = ctx->srt[2].reserve((size_t)W * pl.npad * 8)) != BP_OK) return rc;
         if ((rc = ctx->srt[4].reserve((size_t)W * NB * sizeof(xyzz))) != BP_OK) return rc;
         if ((rc = ctx->srt[5].reserve((size_t)W * pl.nseg * sizeof(xyzz))) != BP_OK) return rc;
@@ -195,24 +223,32 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
         SortedBufs b;
         b.cnt = (uint32_t*)ctx->srt[0].p;
         b.bstart = (uint32_t*)ctx->srt[1].p;
-        b.queue = b.bstart + (size_t)W * (NB + 1);
         b.ent = (uint2*)ctx->srt[2].p;
         b.Bk = (xyzz*)ctx->srt[4].p;
         b.Pseg = (xyzz*)ctx->srt[5].p;
         b.RC = (xyzz*)ctx->srt[6].p;
         HIPCHK(launch_glv_digits(d_scalars_be, n, pl.npad, pl.c, pl.W, (int16_t*)ctx->digits.p, st), "digits");
-        // large MSMs: overlap the top windows' latency-bound tail with the low windows' accumulation
-        // (not when the caller wants every raw window sum: the multi-GPU partials)
-        int split_w = 0;
-        if (!want_c && n2 >= ((size_t)1 << 17)) split_w = W / 2;  // measured at 2^20 / 2^22: +3..4 %
-        if (const char* e = getenv("BP_MSM_SPLIT")) split_w = want_c ? 0 : atoi(e);
-        if (split_w > 0 && !ctx->stream2) {
-            HIPCHK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking), "hipStreamCreate");
-            HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming), "hipEventCreate");
-            HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming), "hipEventCreate");
+        // large MSMs: window groups, top-down; every group's latency-bound tail (bucket reduction, Horner chain)
+        // overlaps the following groups' accumulation (not when the caller wants every raw window sum: the
+        // multi-GPU partials)
+        int gsz[SortedStreams::kMaxGroups];
+        int ng = 0;
+        if (!want_c && n2 >= ((size_t)1 << 17)) ng = plan_window_groups(W, gsz);
+        if (ng > 1 && !ctx->srt_streams) {
+            SortedStreams* ss = new SortedStreams();
+            memset(ss, 0, sizeof(*ss));
+            ctx->srt_streams = ss;
+            HIPCHK(hipStreamCreateWithFlags(&ss->st2, hipStreamNonBlocking), "hipStreamCreate");
+            HIPCHK(hipStreamCreateWithFlags(&ss->st3, hipStreamNonBlocking), "hipStreamCreate");
+            for (int g = 0; g < SortedStreams::kMaxGroups; g++) {
+                HIPCHK(hipEventCreateWithFlags(&ss->ev_acc[g], hipEventDisableTiming), "hipEventCreate");
+                HIPCHK(hipEventCreateWithFlags(&ss->ev_red[g], hipEventDisableTiming), "hipEventCreate");
+                HIPCHK(hipEventCreateWithFlags(&ss->ev_sorted[g], hipEventDisableTiming), "hipEventCreate");
+            }
+            HIPCHK(hipEventCreateWithFlags(&ss->ev_join, hipEventDisableTiming), "hipEventCreate");
+            HIPCHK(hipEventCreateWithFlags(&ss->ev_fork, hipEventDisableTiming), "hipEventCreate");
         }
-        HIPCHK(launch_msm_sorted(d_points, lam, n, (const int16_t*)ctx->digits.p, n2, pl, b, (xyzz*)ctx->wsum.p, st, ctx->stream2, ctx->ev_fork,
-                                 ctx->ev_join, split_w, W_out),
+        HIPCHK(launch_msm_sorted(d_points, lam, n, (const int16_t*)ctx->digits.p, n2, pl, b, (xyzz*)ctx->wsum.p, st, ctx->srt_streams, gsz, ng, W_out),
                "sorted msm");
     }
     return BP_OK;
@@ -322,11 +358,20 @@ void bp_ctx_destroy(bp_ctx* ctx) {
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     for (int i = 0; i <= bp_ctx::kMaxProf; i++)
         if (ctx->prof_ev[i]) (void)hipEventDestroy(ctx->prof_ev[i]);
-    if (ctx->stream2) {
-        (void)hipStreamSynchronize(ctx->stream2);
-        (void)hipStreamDestroy(ctx->stream2);
-        (void)hipEventDestroy(ctx->ev_fork);
-        (void)hipEventDestroy(ctx->ev_join);
+    if (SortedStreams* ss = ctx->srt_streams) {
+        if (ss->st2) (void)hipStreamSynchronize(ss->st2);
+        if (ss->st3) (void)hipStreamSynchronize(ss->st3);
+        if (ss->st2) (void)hipStreamDestroy(ss->st2);
+        if (ss->st3) (void)hipStreamDestroy(ss->st3);
+        for (int g = 0; g < SortedStreams::kMaxGroups; g++) {
+            if (ss->ev_acc[g]) (void)hipEventDestroy(ss->ev_acc[g]);
+            if (ss->ev_red[g]) (void)hipEventDestroy(ss->ev_red[g]);
+            if (ss->ev_sorted[g]) (void)hipEventDestroy(ss->ev_sorted[g]);
+        }
+        if (ss->ev_join) (void)hipEventDestroy(ss->ev_join);
+        if (ss->ev_fork) (void)hipEventDestroy(ss->ev_fork);
+        delete ss;
+        ctx->srt_streams = nullptr;
     }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;

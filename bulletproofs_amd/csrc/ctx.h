@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "ec.h"
+#include "kernels.h"
 
 namespace bp {
 
@@ -33,8 +34,8 @@ void set_error_msg(const char* msg);
 struct bp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // large MSMs: the top windows' reduction + Horner chain overlaps the low windows' accumulation
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // large MSMs: window groups' bucket reduction (st3) and Horner chain (st2) overlap the next groups' accumulation
+    bp::SortedStreams* srt_streams = nullptr;
     int* d_err = nullptr;
     int forced_c = 0;
     int msm_path = 0;  // 0 auto, 1 LDS slice path, 2 sorted path (bp_msm_set_path)

@@ -32,13 +32,18 @@ struct SortedPlan {
     size_t npad;
 };
 struct SortedBufs {
-    uint32_t *cnt, *bstart, *queue;
+    uint32_t *cnt, *bstart;
     uint2* ent;
     xyzz *Bk, *Pseg, *RC;
 };
+// second/third stream + events of the grouped pipeline (see launch_msm_sorted)
+struct SortedStreams {
+    static const int kMaxGroups = 8;
+    hipStream_t st2, st3;
+    hipEvent_t ev_acc[kMaxGroups], ev_red[kMaxGroups], ev_sorted[kMaxGroups], ev_join, ev_fork;
+};
 hipError_t launch_msm_sorted(const affine_mem* pts, const affine_mem* lam, size_t n1, const int16_t* digits, size_t n2, const SortedPlan& pl,
-                             const SortedBufs& b, xyzz* wsum, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, int split_w,
-                             int* W_eff);
+                             const SortedBufs& b, xyzz* wsum, hipStream_t st, const SortedStreams* ss, const int* gsz, int ng, int* W_eff);
 
 // gens_kernels.hip
 hipError_t launch_gens_bases(const affine_mem* pts, int np, int c, int W, xyzz* bases, hipStream_t st);

@@ -313,9 +313,10 @@ __global__ __launch_bounds__(64) void k_msm_reduce_parts(const xyzz* __restrict_
 
 // result = init + sum_w 2^(c*w) wsum[w]  (Horner, one lane: the doubling chain is inherently serial),
 // normalised to the canonical affine element and written as 64 big-endian bytes.
-__global__ void k_msm_horner(const xyzz* __restrict__ wsum, int W, int c, const affine_mem* __restrict__ init, affine_mem* __restrict__ out_limbs,
+__global__ __launch_bounds__(64) void k_msm_horner(const xyzz* __restrict__ wsum, int W, int c, const affine_mem* __restrict__ init, affine_mem* __restrict__ out_limbs,
                              uint8_t* __restrict__ out_be) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __builtin_amdgcn_s_setprio(3);
     xyzz acc = wsum[W - 1];
     for (int w = W - 2; w >= 0; w--) {
         acc = xyzz_dbl_n(acc, c);

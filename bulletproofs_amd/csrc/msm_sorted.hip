@@ -14,14 +14,15 @@
 //                  performs exactly L mixed additions whatever the bucket sizes are.  A run that starts
 //                  inside the segment is the beginning of its bucket and is written to Bk[bucket]; the
 //                  run at the segment start goes to Pseg[segment].
-//   k_srt_finalize one lane per bucket: Bk[b] (+)= the Pseg of every segment boundary inside the bucket;
-//                  buckets spanning many segments are queued and summed by one workgroup each (k_srt_finalize_big)
-//   k_srt_rowcol   bucket index b = hi*LO + lo: row sums R_hi and column sums C_lo, one wave each
+//   k_srt_rowcol2  bucket index b = hi*LO + lo: row sums R_hi and column sums C_lo, one workgroup each, taken
+//                  directly from Bk and Pseg (a sum over buckets needs their partials in no particular order,
+//                  so there is no per-bucket finalize pass)
 //   k_srt_window   sum_b (b+1) B_b = sum_lo lo*C_lo + sum_hi (LO*hi + 1) R_hi by an in-LDS suffix scan
 //
 // No atomics on group elements; the order of additions inside a bucket depends on the LDS cursor
 // race in k_srt_scatter, which cannot change the (canonical, affine) result.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "ec.h"
 #include "kernels.h"
@@ -30,10 +31,10 @@ namespace bp {
 
 #define SRT_T 1024
 
-__global__ __launch_bounds__(SRT_T) void k_srt_hist(const int16_t* __restrict__ digits, size_t n2, size_t npad, int CH, int NB,
+__global__ __launch_bounds__(SRT_T) void k_srt_hist(const int16_t* __restrict__ digits, size_t n2, size_t npad, int CH, int NB, int w0,
                                                     uint32_t* __restrict__ cnt) {
     extern __shared__ uint32_t srt_h[];
-    const int tid = threadIdx.x, chunk = blockIdx.x, w = blockIdx.y, nchunks = gridDim.x;
+    const int tid = threadIdx.x, chunk = blockIdx.x, w = w0 + blockIdx.y, nchunks = gridDim.x;
     for (int b = tid; b < NB; b += SRT_T) srt_h[b] = 0;
     __syncthreads();
     const size_t base = (size_t)chunk * CH;
@@ -49,8 +50,8 @@ __global__ __launch_bounds__(SRT_T) void k_srt_hist(const int16_t* __restrict__ 
 }
 
 // cnt[w][chunk][b] -> exclusive prefix over chunks (in place); sz[w][b] = bucket size
-__global__ void k_srt_colscan(uint32_t* __restrict__ cnt, int nchunks, int NB, uint32_t* __restrict__ sz) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+__global__ void k_srt_colscan(uint32_t* __restrict__ cnt, int nchunks, int NB, int w0, uint32_t* __restrict__ sz) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x, w = w0 + blockIdx.y;
     if (b >= NB) return;
     uint32_t tot = 0;
     for (int ch = 0; ch < nchunks; ch++) {
@@ -63,9 +64,9 @@ __global__ void k_srt_colscan(uint32_t* __restrict__ cnt, int nchunks, int NB, u
 }
 
 // in place: sizes -> exclusive starts, entry NB = number of non-zero digits of the window
-__global__ __launch_bounds__(SRT_T) void k_srt_bstart(uint32_t* __restrict__ bstart, int NB) {
+__global__ __launch_bounds__(SRT_T) void k_srt_bstart(uint32_t* __restrict__ bstart, int NB, int w0) {
     __shared__ uint32_t ts[SRT_T];
-    const int tid = threadIdx.x, w = blockIdx.x;
+    const int tid = threadIdx.x, w = w0 + blockIdx.x;
     uint32_t* a = bstart + (size_t)w * (NB + 1);
     const int per = (NB + SRT_T - 1) / SRT_T;
     int lo = tid * per, hi = lo + per;
@@ -91,11 +92,11 @@ __global__ __launch_bounds__(SRT_T) void k_srt_bstart(uint32_t* __restrict__ bst
     if (tid == SRT_T - 1) a[NB] = ts[SRT_T - 1];
 }
 
-__global__ __launch_bounds__(SRT_T) void k_srt_scatter(const int16_t* __restrict__ digits, size_t n2, size_t npad, int CH, int NB,
+__global__ __launch_bounds__(SRT_T) void k_srt_scatter(const int16_t* __restrict__ digits, size_t n2, size_t npad, int CH, int NB, int w0,
                                                        const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bstart,
                                                        uint2* __restrict__ ent) {
     extern __shared__ uint32_t srt_h[];
-    const int tid = threadIdx.x, chunk = blockIdx.x, w = blockIdx.y, nchunks = gridDim.x;
+    const int tid = threadIdx.x, chunk = blockIdx.x, w = w0 + blockIdx.y, nchunks = gridDim.x;
     const uint32_t* o = cnt + ((size_t)w * nchunks + chunk) * NB;
     const uint32_t* bs = bstart + (size_t)w * (NB + 1);
     for (int b = tid; b < NB; b += SRT_T) srt_h[b] = bs[b] + o[b];
@@ -152,107 +153,29 @@ __global__ __launch_bounds__(256, 2) void k_srt_acc(const affine_mem* __restrict
         Bk[(size_t)w * NB + cur] = acc;
 }
 
-// Buckets with at most SRT_BIG segment partials are summed by their own lane; larger ones (skewed
-// digit distributions: the short top window, +-1 / small scalars) are queued for k_srt_finalize_big
-// so that no lane runs a long serial chain of additions.
-#define SRT_BIG 16
-__global__ __launch_bounds__(256, 2) void k_srt_finalize(const uint32_t* __restrict__ bstart, int NB, int L, int nseg, int w0, int nw,
-                                                         xyzz* __restrict__ Bk, const xyzz* __restrict__ Pseg, uint32_t* __restrict__ queue) {
-    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int w = w0 + (int)(g / NB), b = (int)(g % NB);
-    if (w >= w0 + nw) return;
-    const uint32_t s = bstart[(size_t)w * (NB + 1) + b], e = bstart[(size_t)w * (NB + 1) + b + 1];
-    xyzz r = xyzz_inf();
-    if (e > s) {
-        const uint32_t t0 = (s + L - 1) / L;
-        const uint32_t t1 = (e + L - 1) / L;  // segments t0 .. t1-1 start inside [s, e)
-        if (t1 > t0 + SRT_BIG) {
-            uint32_t q = atomicAdd(&queue[0], 1u);
-            queue[1 + q] = (uint32_t)w * (uint32_t)NB + (uint32_t)b;
-            return;
-        }
-        if (s % L) r = Bk[(size_t)w * NB + b];
-        for (uint32_t t = t0; t < t1; t++) {
-            xyzz o = Pseg[(size_t)w * nseg + t];
-            xyzz_add(r, o);
-        }
-    }
-    Bk[(size_t)w * NB + b] = r;
-}
-
-// one 256-lane workgroup per queued bucket: lanes stride over the bucket's segment partials, LDS tree,
-// lane 0 stores (a bucket holding every entry of a window, 2^21 / L partials, costs 256 + 8 addition steps)
-__global__ __launch_bounds__(256) void k_srt_finalize_big(const uint32_t* __restrict__ bstart, int NB, int L, int nseg, xyzz* __restrict__ Bk,
-                                                          const xyzz* __restrict__ Pseg, const uint32_t* __restrict__ queue) {
-    __shared__ xyzz red[256];
-    const int lane = threadIdx.x;
-    const uint32_t nq = queue[0];
-    for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
-        const uint32_t g = queue[1 + q];
-        const int w = (int)(g / NB), b = (int)(g % NB);
-        const uint32_t s = bstart[(size_t)w * (NB + 1) + b], e = bstart[(size_t)w * (NB + 1) + b + 1];
-        const uint32_t t0 = (s + L - 1) / L, t1 = (e + L - 1) / L;
-        xyzz r = xyzz_inf();
-        if (lane == 0 && (s % L)) r = Bk[(size_t)w * NB + b];
-        for (uint32_t t = t0 + lane; t < t1; t += 256) {
-            xyzz o = Pseg[(size_t)w * nseg + t];
-            xyzz_add(r, o);
-        }
-        red[lane] = r;
-        __syncthreads();
-        for (int off = 128; off >= 1; off >>= 1) {
-            if (lane < off) {
-                xyzz v = red[lane];
-                xyzz u = red[lane + off];
-                xyzz_add(v, u);
-                red[lane] = v;
-            }
-            __syncthreads();
-        }
-        if (lane == 0) Bk[(size_t)w * NB + b] = red[0];
-        __syncthreads();
-    }
-}
-
-// one wave per output: o < LO -> C_o = sum_hi B[hi*LO + o];  o >= LO -> R_(o-LO) = sum_lo B[(o-LO)*LO + lo]
-__global__ __launch_bounds__(256) void k_srt_rowcol(const xyzz* __restrict__ Bk, int NB, int lo_bits, int w0, xyzz* __restrict__ RC) {
-    __shared__ xyzz red[256];
-    const int tid = threadIdx.x, lane = tid & 63, w = w0 + blockIdx.y;
-    const int LO = 1 << lo_bits, HI = NB >> lo_bits, nout = LO + HI;
-    const int o = blockIdx.x * 4 + (tid >> 6);
-    const xyzz* B = Bk + (size_t)w * NB;
-    xyzz acc = xyzz_inf();
-    if (o < LO) {
-        for (int hi = lane; hi < HI; hi += 64) {
-            xyzz v = B[(size_t)hi * LO + o];
-            xyzz_add(acc, v);
-        }
-    } else if (o < nout) {
-        for (int lo = lane; lo < LO; lo += 64) {
-            xyzz v = B[(size_t)(o - LO) * LO + lo];
-            xyzz_add(acc, v);
-        }
-    }
-    red[tid] = acc;
-    __syncthreads();
-    for (int off = 32; off >= 1; off >>= 1) {
-        if (lane < off) {
-            xyzz v = red[tid];
-            xyzz u = red[tid + off];
-            xyzz_add(v, u);
-            red[tid] = v;
-        }
-        __syncthreads();
-    }
-    if (lane == 0 && o < nout) RC[(size_t)w * nout + o] = red[tid];
+// Bucket grid of one window.  A window whose entries all lie in the first NBe = NB / 2^j buckets (always the
+// short top window of a GLV half-scalar; any window when the scalars are small) is reduced over an NBe-bucket
+// grid b = hi * LOe + lo, so that its few, large buckets spread over all rows and columns instead of a handful.
+// Both reduction kernels derive the same grid from bstart (uniform loads).
+__device__ __forceinline__ void srt_grid(const uint32_t* __restrict__ bs, int NB, int& lo_bits, int& NBe) {
+    const uint32_t Nw = bs[NB];
+    int nbits = 31 - __builtin_clz((unsigned)NB);
+    while (nbits > 1 && bs[1 << (nbits - 1)] == Nw) nbits--;
+    NBe = 1 << nbits;
+    if (NBe != NB) lo_bits = (nbits + 1) / 2;
 }
 
 // wsum[w] = sum_{lo >= 1} suffixC[lo] + 2^lo_bits * sum_{hi >= 1} suffixR[hi] + suffixR[0];  LO + HI <= 256
-__global__ __launch_bounds__(256) void k_srt_window(const xyzz* __restrict__ RC, int NB, int lo_bits, int w0, xyzz* __restrict__ wsum) {
+__global__ __launch_bounds__(256) void k_srt_window(const uint32_t* __restrict__ bstart, const xyzz* __restrict__ RC, int NB, int lo_bits, int w0,
+                                                       xyzz* __restrict__ wsum) {
     __shared__ xyzz red[256];
+    __builtin_amdgcn_s_setprio(3);  // latency-bound: issue ahead of the co-resident accumulation waves
     const int tid = threadIdx.x, w = w0 + blockIdx.x;
-    const int LO = 1 << lo_bits, HI = NB >> lo_bits, nout = LO + HI;
-    xyzz v = tid < nout ? RC[(size_t)w * nout + tid] : xyzz_inf();
+    const int stride = (1 << lo_bits) + (NB >> lo_bits);
+    int NBe;
+    srt_grid(bstart + (size_t)w * (NB + 1), NB, lo_bits, NBe);
+    const int LO = 1 << lo_bits, HI = NBe >> lo_bits, nout = LO + HI;
+    xyzz v = tid < nout ? RC[(size_t)w * stride + tid] : xyzz_inf();
     red[tid] = v;
     __syncthreads();
     const int lim = tid < LO ? LO : nout;
@@ -290,8 +213,9 @@ __global__ __launch_bounds__(256) void k_srt_window(const xyzz* __restrict__ RC,
 
 // wsum[w_lo] = sum_{w_lo <= w < w_hi} 2^(c (w - w_lo)) wsum[w]: Horner over the top windows, one lane,
 // so that this serial chain can run on a second stream while the low windows are still accumulating.
-__global__ void k_srt_horner_part(xyzz* __restrict__ wsum, int w_lo, int w_hi, int c) {
+__global__ __launch_bounds__(64) void k_srt_horner_part(xyzz* __restrict__ wsum, int w_lo, int w_hi, int c) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __builtin_amdgcn_s_setprio(3);
     xyzz acc = wsum[w_hi - 1];
     for (int w = w_hi - 2; w >= w_lo; w--) {
         acc = xyzz_dbl_n(acc, c);
@@ -301,59 +225,176 @@ __global__ void k_srt_horner_part(xyzz* __restrict__ wsum, int w_lo, int w_hi, i
     wsum[w_lo] = acc;
 }
 
-// bucket accumulation + reduction of the windows [w0, w0 + nw) on stream st
+// Row and column sums straight from k_srt_acc's outputs (no per-bucket finalize pass): the sum over a set of
+// buckets only needs every partial that belongs to one of them - Bk[b] (the run that starts inside a segment)
+// and the Pseg[t] of every segment that starts inside the bucket - in any order.  One 256-lane workgroup per
+// output: o < LO -> C_o = sum_hi bucket[hi*LO + o];  o >= LO -> R_(o-LO) = sum_lo bucket[(o-LO)*LO + lo].
+// A row's segments are one contiguous range; a column gives each of its HI buckets 256/HI lanes, and buckets
+// with many segments (the short top window, skewed scalars) are summed by the whole workgroup afterwards.
+// Depth: ~2-3 additions per lane + an 8-level LDS tree, whatever the bucket sizes are.
+__global__ __launch_bounds__(256) void k_srt_rowcol2(const uint32_t* __restrict__ bstart, const xyzz* __restrict__ Bk,
+                                                        const xyzz* __restrict__ Pseg, int NB, int L, int nseg, int lo_bits, int w0,
+                                                        xyzz* __restrict__ RC) {
+    __shared__ xyzz red[256];
+    __builtin_amdgcn_s_setprio(3);  // latency-bound: issue ahead of the co-resident accumulation waves
+    __shared__ uint32_t big_t0[256], big_t1[256];
+    __shared__ uint32_t nbig;
+    const int tid = threadIdx.x, w = w0 + blockIdx.y, o = blockIdx.x;
+    const int stride = (1 << lo_bits) + (NB >> lo_bits);
+    const uint32_t* bs = bstart + (size_t)w * (NB + 1);
+    int NBe;
+    srt_grid(bs, NB, lo_bits, NBe);
+    const int LO = 1 << lo_bits, HI = NBe >> lo_bits, nout = LO + HI;
+    if (o >= nout) return;
+    const xyzz* B = Bk + (size_t)w * NB;
+    const xyzz* P = Pseg + (size_t)w * nseg;
+    const uint32_t uL = (uint32_t)L;
+    xyzz acc = xyzz_inf();
+    if (tid == 0) nbig = 0;
+    __syncthreads();
+    if (o >= LO) {
+        const int b0 = (o - LO) * LO;
+        for (int i = tid; i < LO; i += 256) {
+            const uint32_t s = bs[b0 + i], e = bs[b0 + i + 1];
+            if (e > s && (s % uL)) {
+                xyzz v = B[b0 + i];
+                xyzz_add(acc, v);
+            }
+        }
+        const uint32_t t0 = (bs[b0] + uL - 1) / uL, t1 = (bs[b0 + LO] + uL - 1) / uL;
+        for (uint32_t t = t0 + tid; t < t1; t += 256) {
+            xyzz v = P[t];
+            xyzz_add(acc, v);
+        }
+    } else {
+        const int Q = HI >= 256 ? 1 : 256 / HI;  // lanes per bucket
+        for (int h0 = 0; h0 < HI; h0 += 256) {
+            const int hi = h0 + tid / Q, sub = tid % Q;
+            if (hi < HI) {
+                const int b = hi * LO + o;
+                const uint32_t s = bs[b], e = bs[b + 1];
+                if (e > s) {
+                    if (sub == 0 && (s % uL)) {
+                        xyzz v = B[b];
+                        xyzz_add(acc, v);
+                    }
+                    const uint32_t t0 = (s + uL - 1) / uL, t1 = (e + uL - 1) / uL;
+                    if (t1 - t0 <= (uint32_t)(4 * Q)) {
+                        for (uint32_t t = t0 + sub; t < t1; t += Q) {
+                            xyzz v = P[t];
+                            xyzz_add(acc, v);
+                        }
+                    } else if (sub == 0) {
+                        const uint32_t q = atomicAdd(&nbig, 1u);
+                        big_t0[q] = t0;
+                        big_t1[q] = t1;
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t nq = nbig;
+            for (uint32_t q = 0; q < nq; q++) {
+                const uint32_t t1 = big_t1[q];
+                for (uint32_t t = big_t0[q] + tid; t < t1; t += 256) {
+                    xyzz v = P[t];
+                    xyzz_add(acc, v);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) nbig = 0;
+            __syncthreads();
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) {
+            xyzz v = red[tid];
+            xyzz u = red[tid + off];
+            xyzz_add(v, u);
+            red[tid] = v;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) RC[(size_t)w * stride + o] = red[0];
+}
+
+// counting sort by bucket of the windows [w0, w0 + nw) on stream st
+static void srt_sort_windows(const int16_t* digits, size_t n2, const SortedPlan& pl, const SortedBufs& b, int w0, int nw, hipStream_t st) {
+    const int NB = pl.NB;
+    const size_t lds = (size_t)NB * 4;
+    dim3 gcw((unsigned)pl.nchunks, (unsigned)nw);
+    hipLaunchKernelGGL(k_srt_hist, gcw, dim3(SRT_T), lds, st, digits, n2, pl.npad, pl.CH, NB, w0, b.cnt);
+    hipLaunchKernelGGL(k_srt_colscan, dim3((unsigned)((NB + 255) / 256), (unsigned)nw), dim3(256), 0, st, b.cnt, pl.nchunks, NB, w0, b.bstart);
+    hipLaunchKernelGGL(k_srt_bstart, dim3((unsigned)nw), dim3(SRT_T), 0, st, b.bstart, NB, w0);
+    hipLaunchKernelGGL(k_srt_scatter, gcw, dim3(SRT_T), lds, st, digits, n2, pl.npad, pl.CH, NB, w0, b.cnt, b.bstart, b.ent);
+}
+// bucket accumulation of the windows [w0, w0 + nw) on stream st
 static void srt_acc_windows(const affine_mem* pts, const affine_mem* lam, size_t n1, const SortedPlan& pl, const SortedBufs& b, int w0, int nw,
                             hipStream_t st) {
     size_t nthr = (size_t)nw * pl.nseg;
     hipLaunchKernelGGL(k_srt_acc, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, pts, lam, n1, b.ent, b.bstart, pl.npad, pl.NB, pl.L,
                        pl.nseg, w0, nw, b.Bk, b.Pseg);
 }
-static hipError_t srt_reduce_windows(const SortedPlan& pl, const SortedBufs& b, int w0, int nw, uint32_t* queue, xyzz* wsum, hipStream_t st) {
+// bucket reduction of the windows [w0, w0 + nw): wsum[w] = sum_b (b+1) bucket_w[b]
+static hipError_t srt_reduce_windows(const SortedPlan& pl, const SortedBufs& b, int w0, int nw, xyzz* wsum, hipStream_t st) {
     const int NB = pl.NB;
-    hipError_t e = hipMemsetAsync(queue, 0, sizeof(uint32_t), st);
-    if (e != hipSuccess) return e;
-    size_t nthr = (size_t)nw * NB;
-    hipLaunchKernelGGL(k_srt_finalize, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, b.bstart, NB, pl.L, pl.nseg, w0, nw, b.Bk, b.Pseg,
-                       queue);
-    hipLaunchKernelGGL(k_srt_finalize_big, dim3(2048), dim3(256), 0, st, b.bstart, NB, pl.L, pl.nseg, b.Bk, b.Pseg, queue);
     const int nout = (1 << pl.lo_bits) + (NB >> pl.lo_bits);
-    hipLaunchKernelGGL(k_srt_rowcol, dim3((unsigned)((nout + 3) / 4), (unsigned)nw), dim3(256), 0, st, b.Bk, NB, pl.lo_bits, w0, b.RC);
-    hipLaunchKernelGGL(k_srt_window, dim3((unsigned)nw), dim3(256), 0, st, b.RC, NB, pl.lo_bits, w0, wsum);
+    hipLaunchKernelGGL(k_srt_rowcol2, dim3((unsigned)nout, (unsigned)nw), dim3(256), 0, st, b.bstart, b.Bk, b.Pseg, NB, pl.L, pl.nseg, pl.lo_bits,
+                       w0, b.RC);
+    hipLaunchKernelGGL(k_srt_window, dim3((unsigned)nw), dim3(256), 0, st, b.bstart, b.RC, NB, pl.lo_bits, w0, wsum);
     return hipGetLastError();
 }
 
-// Window sums of the sorted path.  With a second stream (st2 + events) and split_w > 0, the windows
-// [split_w, W) are accumulated first; their latency-bound tail (finalize, row/column sums, the window
-// scan and the Horner chain over them) then runs on st2 while the windows [0, split_w) accumulate on st.
-// On return (stream order of st) wsum[0 .. *W_eff) are the window sums to combine:
-// *W_eff = W without the split, split_w + 1 with it (wsum[split_w] = the combined top part).
+// Window sums of the sorted path.
+// ng <= 1: every window accumulated and reduced on st; wsum[0 .. W) are the window sums, *W_eff = W.
+// ng >= 2 (needs ss): the windows are processed top-down in groups of gsz[0], gsz[1], ... windows.  The groups
+// accumulate back to back on st; each group's latency-bound tail runs beside the next groups' accumulation:
+// its bucket reduction on ss->st3 and the Horner chain over the finished groups (running value in
+// wsum[lowest finished window]) on ss->st2.  Only the last group's tail is exposed.  On return (stream order
+// of st) wsum[0] is the complete combination sum_w 2^(c w) S_w and *W_eff = 1.
 hipError_t launch_msm_sorted(const affine_mem* pts, const affine_mem* lam, size_t n1, const int16_t* digits, size_t n2, const SortedPlan& pl,
-                             const SortedBufs& b, xyzz* wsum, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, int split_w,
-                             int* W_eff) {
-    const int NB = pl.NB, W = pl.W;
-    const size_t lds = (size_t)NB * 4;
-    dim3 gcw((unsigned)pl.nchunks, (unsigned)W);
-    hipLaunchKernelGGL(k_srt_hist, gcw, dim3(SRT_T), lds, st, digits, n2, pl.npad, pl.CH, NB, b.cnt);
-    hipLaunchKernelGGL(k_srt_colscan, dim3((unsigned)((NB + 255) / 256), (unsigned)W), dim3(256), 0, st, b.cnt, pl.nchunks, NB, b.bstart);
-    hipLaunchKernelGGL(k_srt_bstart, dim3((unsigned)W), dim3(SRT_T), 0, st, b.bstart, NB);
-    hipLaunchKernelGGL(k_srt_scatter, gcw, dim3(SRT_T), lds, st, digits, n2, pl.npad, pl.CH, NB, b.cnt, b.bstart, b.ent);
+                             const SortedBufs& b, xyzz* wsum, hipStream_t st, const SortedStreams* ss, const int* gsz, int ng, int* W_eff) {
+    const int W = pl.W;
     hipError_t e;
-    if (!st2 || split_w <= 0 || split_w >= W - 1) {
+    if (!ss || ng <= 1) {
+        srt_sort_windows(digits, n2, pl, b, 0, W, st);
         srt_acc_windows(pts, lam, n1, pl, b, 0, W, st);
         *W_eff = W;
-        return srt_reduce_windows(pl, b, 0, W, b.queue, wsum, st);
+        return srt_reduce_windows(pl, b, 0, W, wsum, st);
     }
-    uint32_t* queue2 = b.queue + ((size_t)W * NB + 1);
-    srt_acc_windows(pts, lam, n1, pl, b, split_w, W - split_w, st);
-    if ((e = hipEventRecord(ev_fork, st)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(st2, ev_fork, 0)) != hipSuccess) return e;
-    if ((e = srt_reduce_windows(pl, b, split_w, W - split_w, queue2, wsum, st2)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_srt_horner_part, dim3(1), dim3(64), 0, st2, wsum, split_w, W, pl.c);
-    if ((e = hipEventRecord(ev_join, st2)) != hipSuccess) return e;
-    srt_acc_windows(pts, lam, n1, pl, b, 0, split_w, st);
-    if ((e = srt_reduce_windows(pl, b, 0, split_w, b.queue, wsum, st)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(st, ev_join, 0)) != hipSuccess) return e;
-    *W_eff = split_w + 1;
+    // Counting sort: either every window up front, or (presort = false) the top group's windows first and the
+    // other groups' on st2, group by group, beside the accumulation of the groups before them.
+    const bool presort = getenv("BP_MSM_PRESORT") ? atoi(getenv("BP_MSM_PRESORT")) != 0 : false;
+    if (presort) {
+        srt_sort_windows(digits, n2, pl, b, 0, W, st);
+    } else {
+        srt_sort_windows(digits, n2, pl, b, W - gsz[0], gsz[0], st);
+        if ((e = hipEventRecord(ss->ev_fork, st)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(ss->st2, ss->ev_fork, 0)) != hipSuccess) return e;
+        for (int g = 1, top = W - gsz[0]; g < ng; g++) {
+            srt_sort_windows(digits, n2, pl, b, top - gsz[g], gsz[g], ss->st2);
+            if ((e = hipEventRecord(ss->ev_sorted[g], ss->st2)) != hipSuccess) return e;
+            top -= gsz[g];
+        }
+    }
+    int hi = W;
+    for (int g = 0; g < ng; g++) {
+        const int lo = hi - gsz[g];
+        if (g >= 1 && !presort && (e = hipStreamWaitEvent(st, ss->ev_sorted[g], 0)) != hipSuccess) return e;
+        srt_acc_windows(pts, lam, n1, pl, b, lo, hi - lo, st);
+        if ((e = hipEventRecord(ss->ev_acc[g], st)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(ss->st3, ss->ev_acc[g], 0)) != hipSuccess) return e;
+        if ((e = srt_reduce_windows(pl, b, lo, hi - lo, wsum, ss->st3)) != hipSuccess) return e;
+        if ((e = hipEventRecord(ss->ev_red[g], ss->st3)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(ss->st2, ss->ev_red[g], 0)) != hipSuccess) return e;
+        // wsum[lo] = sum over the windows >= lo (wsum[hi] holds the previous groups' combination)
+        hipLaunchKernelGGL(k_srt_horner_part, dim3(1), dim3(64), 0, ss->st2, wsum, lo, g ? hi + 1 : hi, pl.c);
+        hi = lo;
+    }
+    if ((e = hipEventRecord(ss->ev_join, ss->st2)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(st, ss->ev_join, 0)) != hipSuccess) return e;
+    *W_eff = 1;
     return hipGetLastError();
 }
 

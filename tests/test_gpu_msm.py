@@ -132,6 +132,32 @@ def test_msm_linearity_large(ctx, oracle_c):
             ctx.set_path(0)
 
 
+def test_msm_grouped_pipeline_skewed_scalars(ctx, oracle_c):
+    """The grouped, multi-stream pipeline of the sorted path (n >= 2^16: window groups top-down, bucket reduction
+    and Horner chain beside the next group's accumulation, per-window bucket grid) on scalar distributions that
+    leave windows empty, fill single buckets, or fill only the lowest buckets of a window:
+    sum k_i (r_j G) == (sum k_i r_j) G."""
+    rng = random.Random(4242)
+    n = 70000
+    rs = [rng.randrange(1, ec.Q) for _ in range(64)]
+    base = oracle_c.mul_batch([ec.G] * 64, rs)
+    idx = [rng.randrange(64) for _ in range(n)]
+    pts = [base[i] for i in idx]
+    mixes = {
+        "pm1": lambda: rng.choice([0, 1, ec.Q - 1]),
+        "small": lambda: rng.randrange(1 << 20),
+        "u64": lambda: rng.randrange(1 << 64),
+        "mixed": lambda: rng.choice([rng.randrange(ec.Q), rng.randrange(1 << 40), 1, ec.Q - 2, 0, 1 << 200]),
+        "same": lambda: 0x1234567,
+    }
+    for name, draw in mixes.items():
+        ks = [draw() for _ in range(n)]
+        pb, sb = _pack(pts, ks)
+        want_scalar = sum(ks[i] * rs[idx[i]] for i in range(n)) % ec.Q
+        want = ec.enc64(oracle_c.mul(ec.G, want_scalar)) if want_scalar else bytes(64)
+        assert ctx.msm(pb, sb, None) == want, name
+
+
 def test_msm_full_size_2pow20(ctx, oracle_c):
     """BASELINE.json configs[4] size (2^20 terms): sum k_i (r_i G) == (sum k_i r_i) G with 2^20 distinct
     points r_i G made on the GPU (fixed-base batch) and independent 256-bit scalars."""
