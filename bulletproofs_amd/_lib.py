@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = [
     "bp_fold_bases",
     "bp_fixed_base_mul_batch",
     "bp_generate_bases",
+    "bp_generate_bases_device",
     "bp_rangeproof_prove",
     "bp_rangeproof_verify",
     "bp_wip_rangeproof_prove",
@@ -127,6 +128,8 @@ def lib():
     L.bp_msm_batch.restype = i32
     L.bp_generate_bases.argtypes = [i32, ctypes.c_uint64, sz, sz, cp, cp, cp, cp]
     L.bp_generate_bases.restype = i32
+    L.bp_generate_bases_device.argtypes = [vp, i32, ctypes.c_uint64, sz, sz, cp, cp, cp, cp]
+    L.bp_generate_bases_device.restype = i32
     prove_args = [vp, vp, i32, cp, cp, i32, cp, sz, cp, sz, ctypes.POINTER(sz)]
     verify_args = [vp, vp, i32, i32, cp, sz, cp, i32, cp]
     L.bp_rangeproof_prove.argtypes = prove_args
@@ -314,6 +317,16 @@ class Context:
         out = ctypes.create_string_buffer(max(64 * n, 1))
         _check(lib().bp_fixed_base_mul_batch(self._h, bytes(scalars_be), n, out))
         return out.raw[:64 * n]
+
+    def generate_bases(self, kind, seed, n_bits, m):
+        """`generate_bases` computed on the GPU (bp_generate_bases_device): same bytes as the host recipe."""
+        nm = n_bits * m
+        g = ctypes.create_string_buffer(64 * nm)
+        h = ctypes.create_string_buffer(64 * nm)
+        G = ctypes.create_string_buffer(64)
+        H = ctypes.create_string_buffer(64)
+        _check(lib().bp_generate_bases_device(self._h, kind, seed, n_bits, m, g, h, G, H))
+        return g.raw, h.raw, G.raw, H.raw
 
     def _prove(self, fn, gens, n_bits, secrets_be, blindings_be, tape):
         m = len(secrets_be) // 32

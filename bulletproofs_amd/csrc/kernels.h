@@ -51,6 +51,9 @@ hipError_t launch_xyzz_to_affine(const xyzz* in, affine_mem* out, size_t n, hipS
 hipError_t launch_gens_multiples(const affine_mem* basesA, size_t nidx, int NB, xyzz* tmp, hipStream_t st);
 hipError_t launch_gens_normalize(const xyzz* tmp, size_t n, affine_mem* table, hipStream_t st);
 
+// gens_derive.hip: the reference's synthetic generator recipe, one lane per generator (g_vec, h_vec, G, H order)
+hipError_t launch_gens_derive(int kind, uint64_t seed, uint64_t n_bits, size_t nm, affine_mem* out, hipStream_t st);
+
 // verify_kernels.hip
 hipError_t launch_bpv_decompress(const uint8_t* proofs, size_t proof_len, const uint8_t* coms_xy, int k, int m, size_t nproofs, affine_mem* pts,
                                  int* bad, hipStream_t st);

@@ -636,6 +636,28 @@ int bp_generate_bases(int kind, uint64_t seed, size_t n_bits, size_t m, uint8_t*
     return BP_OK;
 }
 
+// the same recipe on the GPU (gens_derive.hip): one lane per generator, SHA-512 + try-and-double decompression
+int bp_generate_bases_device(bp_ctx* ctx, int kind, uint64_t seed, size_t n_bits, size_t m, uint8_t* g_xy, uint8_t* h_xy, uint8_t G_xy[64],
+                             uint8_t H_xy[64]) {
+    if (!ctx || !g_xy || !h_xy || !G_xy || !H_xy || n_bits == 0 || m == 0 || (kind != 0 && kind != 1)) return BP_EINVAL;
+    if (kind == 1 && seed == 0) return BP_EINVAL;
+    if (n_bits > ((size_t)1 << 20) || m > ((size_t)1 << 20) || n_bits * m > ((size_t)1 << 24)) return BP_EINVAL;
+    const size_t nm = n_bits * m, np = 2 * nm + 2;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    RC(ctx->proto[4].reserve(np * sizeof(affine_mem)));
+    RC(ctx->proto[5].reserve(np * 64));
+    HIPCHK(launch_gens_derive(kind, seed, (uint64_t)n_bits, nm, (affine_mem*)ctx->proto[4].p, ctx->stream), "gens_derive");
+    HIPCHK(launch_export_points((const affine_mem*)ctx->proto[4].p, (uint8_t*)ctx->proto[5].p, np, ctx->stream), "export");
+    const uint8_t* d = (const uint8_t*)ctx->proto[5].p;
+    HIPCHK(hipMemcpyAsync(g_xy, d, nm * 64, hipMemcpyDeviceToHost, ctx->stream), "memcpy g");
+    HIPCHK(hipMemcpyAsync(h_xy, d + nm * 64, nm * 64, hipMemcpyDeviceToHost, ctx->stream), "memcpy h");
+    HIPCHK(hipMemcpyAsync(G_xy, d + 2 * nm * 64, 64, hipMemcpyDeviceToHost, ctx->stream), "memcpy G");
+    HIPCHK(hipMemcpyAsync(H_xy, d + (2 * nm + 1) * 64, 64, hipMemcpyDeviceToHost, ctx->stream), "memcpy H");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "sync");
+    return BP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 int bp_scalar_mul_batch(bp_ctx* ctx, const uint8_t* points_xy, const uint8_t* scalars_be, size_t n, uint8_t* out_xy) {
     if (!ctx || (n && (!points_xy || !scalars_be || !out_xy))) return BP_EINVAL;

@@ -176,6 +176,12 @@ int bp_fixed_base_mul_batch(bp_ctx* ctx, const uint8_t* scalars_be, size_t n, ui
  * grp = generate_random_point (range_proof.rs:785-808).  g_xy / h_xy receive n_bits*m points. */
 int bp_generate_bases(int kind, uint64_t seed, size_t n_bits, size_t m, uint8_t* g_xy, uint8_t* h_xy, uint8_t G_xy[64], uint8_t H_xy[64]);
 
+/* bp_generate_bases_device — the same recipe computed on the GPU, one lane per generator (SHA-512 of the label,
+ * try-and-double decompression of range_proof.rs:785-808): byte-identical outputs, milliseconds instead of
+ * O(nm) host square roots for large aggregations (n_bits*m <= 2^24). */
+int bp_generate_bases_device(bp_ctx* ctx, int kind, uint64_t seed, size_t n_bits, size_t m, uint8_t* g_xy, uint8_t* h_xy, uint8_t G_xy[64],
+                             uint8_t H_xy[64]);
+
 /* bp_rangeproof_prove — `RangeProof::prove` (range_proof.rs:45-263) + `InnerProductArg::prove`
  * (inner_product.rs:36-169).  secrets_be / blindings_be: m scalars of 32 bytes.  The reference draws
  * its randomness from the OS (`Scalar::random()`), so the caller supplies it: `tape` holds 2nm+4

@@ -176,3 +176,24 @@ def test_bpplus_c4_n64_m64(ctx):
         assert ctx.wip_rangeproof_verify(gens, 64, 64, proof, coms, 0) == 0
     finally:
         gens.close()
+
+
+@pytest.mark.parametrize("kind,seed,n,m", [(0, None, 64, 1), (1, None, 64, 1), (0, None, 8, 1), (1, None, 32, 4), (0, 1, 3, 5),
+                                           (1, 1, 1, 1), (0, (1 << 64) - 40, 16, 2), (1, None, 64, 64)])
+def test_generate_bases_on_device_matches_host_and_oracle(ctx, kind, seed, n, m):
+    """SURVEY 8f row 4: generate_random_point / StatementRP::generate_bases (range_proof.rs:785-808, 821-843;
+    range_proof_wip.rs:48-91) on the GPU: byte-identical to the host recipe for every label (about half of them take
+    the try-and-double path, ~1/256 lose a leading zero byte of the SHA-512 digest, labels of 1..8 bytes, label
+    wrap-around at 2^64), and to the oracle's Python restatement on the small cases."""
+    from oracle import curv
+    seed = bpa.KZEN_SEED if seed is None else seed
+    want = bpa.generate_bases(kind, seed, n, m)
+    got = ctx.generate_bases(kind, seed, n, m)
+    assert got == want
+    if n * m <= 64 and seed + 2 * n * m < (1 << 64):
+        def lab(x):
+            return ec.enc64(curv.label_point(x))
+        nm = n * m
+        assert got[0][:64 * min(nm, 8)] == b"".join(lab(seed + i) for i in range(min(nm, 8)))
+        assert got[1][:64 * min(nm, 8)] == b"".join(lab(seed + n + i) for i in range(min(nm, 8)))
+        assert got[3] == lab(1 if kind == 0 else seed - 1)
