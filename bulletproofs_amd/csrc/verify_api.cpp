@@ -187,7 +187,7 @@ int bp_profile_get(bp_ctx* ctx, int kernel_id, double* total_ms, long* launches)
 
 // argument checks shared by the batch verifiers: BP_EINVAL where the reference asserts (range_proof.rs:556-562)
 static int check_batch_args(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len, const void* d_coms_xy,
-                            size_t nproofs, void* d_verdicts, int* k_out) {
+                            size_t nproofs, void* d_verdicts, int* k_out, int wip = 0) {
     if (!ctx || !gens || n_bits <= 0 || n_bits > 128 || m <= 0) return BP_EINVAL;
     if (nproofs && (!d_proofs || !d_coms_xy || !d_verdicts)) return BP_EINVAL;
     size_t nm = (size_t)n_bits * m;
@@ -197,8 +197,8 @@ static int check_batch_args(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
     }
     int k = 0;
     while (((size_t)1 << k) < nm) k++;
-    if (proof_len != (size_t)292 + 66 * (size_t)k || k > 16) {
-        set_error_msg("proof_len != 292 + 66*log2(nm)");
+    if (proof_len != (size_t)(wip ? 195 : 292) + 66 * (size_t)k || k > 16) {
+        set_error_msg(wip ? "proof_len != 195 + 66*log2(nm)" : "proof_len != 292 + 66*log2(nm)");
         return BP_EINVAL;
     }
     *k_out = k;
@@ -206,7 +206,7 @@ static int check_batch_args(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
 }
 
 static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, const void* d_proofs, size_t proof_len,
-                                      const void* d_coms_xy, size_t nproofs, void* d_verdicts);
+                                      const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip = 0);
 
 int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
                                       const void* d_coms_xy, size_t nproofs, void* d_verdicts) {
@@ -217,11 +217,13 @@ int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bi
     return verify_batch_device_nolock(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts);
 }
 
+// wip = 1: Bulletproofs+ (RangeProofWIP::aggregated_verify, range_proof_wip.rs:388-609): own decompression order and
+// scalar pipeline, the same MSM kernel (its variable terms and comparand follow the point order, verify_kernels.hip)
 static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, const void* d_proofs, size_t proof_len,
-                                      const void* d_coms_xy, size_t nproofs, void* d_verdicts) {
+                                      const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip) {
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = ctx->stream;
-    const int NPT = 4 + 2 * k + m, NV = 3 + 2 * k + m;
+    const int NPT = (wip ? 3 : 4) + 2 * k + m, NV = (wip ? 2 : 3) + 2 * k + m;
     int rc;
     DevBuf &b_pts = ctx->scratch[0], &b_bad = ctx->scratch[1], &b_dig = ctx->scratch[2], &b_var = ctx->scratch[3], &b_s = ctx->scratch[4];
     if ((rc = b_pts.reserve(nproofs * NPT * sizeof(affine_mem))) != BP_OK) return rc;
@@ -240,13 +242,25 @@ static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bi
         prof_collect(ctx);
     }
     prof_mark(ctx, 0);
-    HIPCHK(launch_bpv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine_mem*)b_pts.p, (int*)b_bad.p, st),
-           "bpv_decompress");
-    prof_mark(ctx, 1);
-    HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
-                                      gens->d_table, gens->c, gens->W, (tdig_t*)b_dig.p, nullptr, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
+    if (wip)
+        HIPCHK(launch_wipv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine_mem*)b_pts.p,
                                       (int*)b_bad.p, st),
-           "bpv_scalars");
+               "wipv_decompress");
+    else
+        HIPCHK(launch_bpv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine_mem*)b_pts.p,
+                                     (int*)b_bad.p, st),
+               "bpv_decompress");
+    prof_mark(ctx, 1);
+    if (wip)
+        HIPCHK(launch_wipv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
+                                           gens->d_table, gens->c, gens->W, (tdig_t*)b_dig.p, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
+                                           (int*)b_bad.p, st),
+               "wipv_scalars");
+    else
+        HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
+                                          gens->d_table, gens->c, gens->W, (tdig_t*)b_dig.p, nullptr, (fq*)b_var.p, d_chal, d_cst, d_fixres,
+                                          d_fixaff, (int*)b_bad.p, st),
+               "bpv_scalars");
     prof_mark(ctx, 2);
     // lanes per proof: fewer lanes share more doubling chains (less work) but need more proofs in
     // flight to fill 256 CUs x 4 SIMDs x 2 waves
@@ -254,7 +268,7 @@ static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bi
     if (tp != 2 && tp != 4 && tp != 8 && tp != 16 && tp != 32 && tp != 64) tp = nproofs >= 65536 ? 2 : (nproofs >= 32768 ? 4 : (nproofs >= 12288 ? 8 : 16));
     if ((rc = ctx->vartab.reserve(bpv_msm_vartab_bytes(tp, nproofs))) != BP_OK) return rc;
     HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_table, gens->c, gens->W, (const tdig_t*)b_dig.p,
-                          (const fq*)b_var.p, (xyzz*)ctx->vartab.p, (const int*)b_bad.p, (uint8_t*)d_verdicts, st),
+                          (const fq*)b_var.p, (xyzz*)ctx->vartab.p, (const int*)b_bad.p, (uint8_t*)d_verdicts, st, wip),
            "bpv_msm");
     prof_mark(ctx, 3);
     if (ctx->profiling) {
@@ -264,6 +278,15 @@ static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bi
         ctx->prof_n = 3;
     }
     return BP_OK;
+}
+
+int bp_wip_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
+                                          const void* d_coms_xy, size_t nproofs, void* d_verdicts) {
+    int k = 0;
+    int rc = check_batch_args(ctx, gens, n_bits, m, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, &k, 1);
+    if (rc != BP_OK || nproofs == 0) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return verify_batch_device_nolock(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, 1);
 }
 
 // Random-linear-combination batch verification (rlc_kernels.hip).  Synchronous: returns with the verdicts
@@ -467,6 +490,22 @@ int bp_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int
     void *d_p, *d_c, *d_v;
     if (int rcs = stage_batch(ctx, proofs, proof_len, coms_xy, m, nproofs, &d_p, &d_c, &d_v)) return rcs;
     int rc = bp_rangeproof_verify_batch_device(ctx, gens, n_bits, m, d_p, proof_len, d_c, nproofs, d_v);
+    if (rc != BP_OK) return rc;
+    std::vector<uint8_t> tmp(nproofs);
+    HIPCHK(hipMemcpyAsync(tmp.data(), d_v, nproofs, hipMemcpyDeviceToHost, ctx->stream), "memcpy verdicts");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "sync");
+    memcpy(verdicts, tmp.data(), nproofs);
+    return BP_OK;
+}
+
+int bp_wip_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
+                                   const uint8_t* coms_xy, size_t nproofs, uint8_t* verdicts) {
+    if (!ctx || !gens || m <= 0) return BP_EINVAL;
+    if (nproofs == 0) return BP_OK;
+    if (!proofs || !coms_xy || !verdicts) return BP_EINVAL;
+    void *d_p, *d_c, *d_v;
+    if (int rcs = stage_batch(ctx, proofs, proof_len, coms_xy, m, nproofs, &d_p, &d_c, &d_v)) return rcs;
+    int rc = bp_wip_rangeproof_verify_batch_device(ctx, gens, n_bits, m, d_p, proof_len, d_c, nproofs, d_v);
     if (rc != BP_OK) return rc;
     std::vector<uint8_t> tmp(nproofs);
     HIPCHK(hipMemcpyAsync(tmp.data(), d_v, nproofs, hipMemcpyDeviceToHost, ctx->stream), "memcpy verdicts");

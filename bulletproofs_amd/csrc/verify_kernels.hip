@@ -56,6 +56,37 @@ __global__ void k_bpv_decompress(const uint8_t* __restrict__ proofs, size_t proo
     if (!ok) atomicOr(&bad[pr], 1);
 }
 
+// Bulletproofs+ proofs (A | L[k] | R[k] | a_tag b_tag | r' s' delta', oracle/encoding.py) into the point order
+// b_tag, A, L[k], R[k], a_tag, V[m]: the MSM's variable terms are then pts[1..] and the comparand is pts[0].
+__global__ void k_wipv_decompress(const uint8_t* __restrict__ proofs, size_t proof_len, const uint8_t* __restrict__ coms_xy, int k, int m,
+                                  size_t nproofs, affine_mem* __restrict__ pts, int* __restrict__ bad) {
+    const int npc = 3 + 2 * k;
+    const int NPT = npc + m;
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= nproofs * (size_t)NPT) return;
+    size_t pr = gid / NPT;
+    int j = (int)(gid % NPT);  // index in pts
+    affine a;
+    bool ok;
+    if (j < npc) {
+        const int f = (j == 0) ? 2 * k + 2 : j - 1;  // position in the proof: A, L.., R.., a_tag, b_tag
+        const uint8_t* src = proofs + pr * proof_len + (size_t)33 * f;
+        uint8_t b[33];
+        for (int i = 0; i < 33; i++) b[i] = src[i];
+        ok = affine_decompress(a, b);
+        if (!ok) a = affine_inf();
+    } else {
+        const uint8_t* src = coms_xy + (pr * (size_t)m + (j - npc)) * 64;
+        uint8_t b[64];
+        for (int i = 0; i < 64; i++) b[i] = src[i];
+        affine_mem mm = affine_mem_from_be64(b);
+        ok = affine_mem_valid(mm, false);
+        a = ok ? affine_load(mm) : affine_inf();
+    }
+    pts[pr * NPT + j] = affine_store(a);
+    if (!ok) atomicOr(&bad[pr], 1);
+}
+
 // ------------------------------------------------------------------------------------------------
 #ifndef BPV_MSM_WAVES
 #define BPV_MSM_WAVES 2
@@ -67,15 +98,17 @@ template <int TP, int PPL>
 __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int m, int k, size_t nproofs, const affine_mem* __restrict__ pts,
                                                  const affine_mem* __restrict__ table, int c, int W, const tdig_t* __restrict__ digF,
                                                  const fq* __restrict__ varS, xyzz* __restrict__ vartab, int8_t* __restrict__ vardig,
-                                                 const int* __restrict__ bad, uint8_t* __restrict__ verdicts, int dbg_skip) {
+                                                 const int* __restrict__ bad, uint8_t* __restrict__ verdicts, int dbg_skip, int wip) {
     __shared__ xyzz red[256];
     const int tid = threadIdx.x;
     const int lane = tid % TP;
     const size_t pr = (size_t)blockIdx.x * (256 / TP) + tid / TP;
     const bool active = pr < nproofs && !(pr < nproofs && bad[pr]);
     const int nm = n_bits * m;
-    const int NPT = 4 + 2 * k + m;
-    const int NV = 3 + 2 * k + m;
+    // Bulletproofs: pts = A S T1 T2 L[k] R[k] V[m], 3+2k+m variable terms, compared with A.
+    // Bulletproofs+ (wip): pts = b_tag A L[k] R[k] a_tag V[m], variable terms pts[1..], compared with b_tag.
+    const int NPT = (wip ? 3 : 4) + 2 * k + m;
+    const int NV = (wip ? 2 : 3) + 2 * k + m;
     const int NB = 1 << (c - 1);
     xyzz acc = xyzz_inf();
     if (active) {
@@ -100,7 +133,7 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
             // variable point order: S, L_0.., R_0.., V_0.., T1, T2  ->  index into pts
             auto loadP = [&](int j) {
                 int v = v0 + TP * j;
-                int pi = (v == 0) ? 1 : (v < 1 + 2 * k + m) ? (3 + v) : (v == 1 + 2 * k + m ? 2 : 3);
+                int pi = wip ? 1 + v : (v == 0) ? 1 : (v < 1 + 2 * k + m) ? (3 + v) : (v == 1 + 2 * k + m ? 2 : 3);
                 return affine_load(P[pi]);
             };
             auto loadK = [&](int j) { return vs[v0 + TP * j]; };
@@ -124,7 +157,7 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
         if (bad[pr]) {
             verdict = 255;
         } else {
-            // lhs == A ?  (range_proof.rs:777) compared projectively: X = A.x*ZZ, Y = A.y*ZZZ
+            // lhs == A ?  (range_proof.rs:777; == b_tag, range_proof_wip.rs:604) compared projectively: X = A.x*ZZ, Y = A.y*ZZZ
             xyzz r = red[tid];
             affine A = affine_load(pts[pr * NPT]);
             bool eq = !xyzz_is_inf(r) && fp_eq(r.X, fp_mul(A.x, r.ZZ)) && fp_eq(r.Y, fp_mul(A.y, r.ZZZ));
@@ -141,6 +174,13 @@ hipError_t launch_bpv_decompress(const uint8_t* proofs, size_t proof_len, const 
                        bad);
     return hipGetLastError();
 }
+hipError_t launch_wipv_decompress(const uint8_t* proofs, size_t proof_len, const uint8_t* coms_xy, int k, int m, size_t nproofs, affine_mem* pts,
+                                  int* bad, hipStream_t st) {
+    size_t total = nproofs * (size_t)(3 + 2 * k + m);
+    hipLaunchKernelGGL(k_wipv_decompress, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, proofs, proof_len, coms_xy, k, m, nproofs, pts,
+                       bad);
+    return hipGetLastError();
+}
 // lanes per proof -> proof-specific points per lane and pass
 static int bpv_ppl(int tp) { return tp == 2 ? 8 : (tp == 4 ? 4 : (tp == 8 ? 2 : 1)); }
 size_t bpv_msm_vartab_bytes(int tp, size_t nproofs) {
@@ -148,14 +188,14 @@ size_t bpv_msm_vartab_bytes(int tp, size_t nproofs) {
     return blocks * 256 * bpv_ppl(tp) * (ECMUL_SLOTS * sizeof(xyzz) + ECMUL_DIGB);
 }
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
-                          const tdig_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st) {
+                          const tdig_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st, int wip) {
     unsigned blocks = (unsigned)((nproofs + (256 / tp) - 1) / (256 / tp));
     const char* e = getenv("BP_DEBUG_SKIP");  // timing experiments only: 1 = skip fixed part, 2 = skip variable part
     int dbg = e ? atoi(e) : 0;
     int8_t* vardig = reinterpret_cast<int8_t*>(vartab + (size_t)blocks * 256 * bpv_ppl(tp) * ECMUL_SLOTS);
 #define BPV_LAUNCH(TP, PPL)                                                                                                                  \
     hipLaunchKernelGGL((k_bpv_msm<TP, PPL>), dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, vardig, \
-                       bad, verdicts, dbg)
+                       bad, verdicts, dbg, wip)
     if (tp == 2)
         BPV_LAUNCH(2, 8);
     else if (tp == 4)

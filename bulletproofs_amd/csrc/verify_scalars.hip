@@ -216,13 +216,13 @@ __device__ __forceinline__ void store_digits(const fq& kk, int c, int W, tdig_t*
 // (8 lanes per multiplication spent 138M VALU instructions per 16384 proofs, mostly in the tree).
 #define FM_SUB 2
 __global__ __launch_bounds__(256) void k_bpv_fixmul(int k, int nm, size_t nproofs, const affine_mem* __restrict__ table, int c, int W,
-                                                    const fq* __restrict__ chal, xyzz* __restrict__ fixres, const int* __restrict__ bad) {
+                                                    const fq* __restrict__ chal, xyzz* __restrict__ fixres, const int* __restrict__ bad, int nmul) {
     __shared__ xyzz red[256];
     const int tid = threadIdx.x, lane = tid % (2 * FM_SUB), sub = lane % FM_SUB, which = lane / FM_SUB;
     const size_t pr = (size_t)blockIdx.x * (256 / (2 * FM_SUB)) + tid / (2 * FM_SUB);
     const int NB = 1 << (c - 1);
     xyzz acc = xyzz_inf();
-    if (pr < nproofs && !bad[pr]) {
+    if (pr < nproofs && !bad[pr] && which < nmul) {
         fq s = chal[pr * CH_COUNT(k) + (which ? CH_XU : CH_Y)];
         const size_t pG = (size_t)2 * nm;
         uint32_t carry = 0;
@@ -318,6 +318,36 @@ __global__ __launch_bounds__(64) void k_bpv_hash2(int k, int m, size_t nproofs, 
 #define CS_YHI(k, m) (CS_YLO(k, m) + (1 << CS_LOBITS(k)))
 #define CS_COUNT(k, m) (CS_YHI(k, m) + (1 << CS_HIBITS(k)))
 #define BPV_MAXK 16
+
+// split-index tables of k_bpv_vec from x_j, x_j^-1 and y^-(2^t) (already in cs): one product per entry
+// (flipping bit t of the index from x^-1 to x multiplies by x^2)
+__device__ __forceinline__ void bpv_split_tables(fqm* cs, int k, int m) {
+    const fqm ONE = fqm_one();
+    {
+        const int LO = CS_LOBITS(k), HI = CS_HIBITS(k);
+        fqm *slo = cs + CS_SLO(k, m), *shi = cs + CS_SHI(k, m), *ylo = cs + CS_YLO(k, m), *yhi = cs + CS_YHI(k, m);
+        fqm p = ONE;
+        for (int t = 0; t < LO; t++) p = fqm_mul(p, cs[CS_XINV(k) + (k - 1 - t)]);
+        slo[0] = p;
+        ylo[0] = ONE;
+        for (int j = 1; j < (1 << LO); j++) {
+            const int t = 31 - __builtin_clz((unsigned)j);  // top set bit
+            const fqm xm = cs[CS_XJ + (k - 1 - t)];
+            slo[j] = fqm_mul(slo[j - (1 << t)], fqm_mul(xm, xm));
+            ylo[j] = fqm_mul(ylo[j - (1 << t)], cs[CS_YINVP(k) + t]);
+        }
+        p = ONE;
+        for (int t = 0; t < HI; t++) p = fqm_mul(p, cs[CS_XINV(k) + (k - 1 - LO - t)]);
+        shi[0] = p;
+        yhi[0] = ONE;
+        for (int j = 1; j < (1 << HI); j++) {
+            const int t = 31 - __builtin_clz((unsigned)j);
+            const fqm xm = cs[CS_XJ + (k - 1 - LO - t)];
+            shi[j] = fqm_mul(shi[j - (1 << t)], fqm_mul(xm, xm));
+            yhi[j] = fqm_mul(yhi[j - (1 << t)], cs[CS_YINVP(k) + LO + t]);
+        }
+    }
+}
 
 __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
                                                    const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF, fqm* __restrict__ scF,
@@ -422,37 +452,15 @@ __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ p
     cs[CS_Z] = z_m;
     cs[CS_A] = a_m;
     cs[CS_B] = b_m;
-    // split-index tables: one product per entry (flipping bit t of the index from x^-1 to x multiplies by x^2)
-    {
-        const int LO = CS_LOBITS(k), HI = CS_HIBITS(k);
-        fqm *slo = cs + CS_SLO(k, m), *shi = cs + CS_SHI(k, m), *ylo = cs + CS_YLO(k, m), *yhi = cs + CS_YHI(k, m);
-        fqm p = ONE;
-        for (int t = 0; t < LO; t++) p = fqm_mul(p, cs[CS_XINV(k) + (k - 1 - t)]);
-        slo[0] = p;
-        ylo[0] = ONE;
-        for (int j = 1; j < (1 << LO); j++) {
-            const int t = 31 - __builtin_clz((unsigned)j);  // top set bit
-            const fqm xm = cs[CS_XJ + (k - 1 - t)];
-            slo[j] = fqm_mul(slo[j - (1 << t)], fqm_mul(xm, xm));
-            ylo[j] = fqm_mul(ylo[j - (1 << t)], cs[CS_YINVP(k) + t]);
-        }
-        p = ONE;
-        for (int t = 0; t < HI; t++) p = fqm_mul(p, cs[CS_XINV(k) + (k - 1 - LO - t)]);
-        shi[0] = p;
-        yhi[0] = ONE;
-        for (int j = 1; j < (1 << HI); j++) {
-            const int t = 31 - __builtin_clz((unsigned)j);
-            const fqm xm = cs[CS_XJ + (k - 1 - LO - t)];
-            shi[j] = fqm_mul(shi[j - (1 << t)], fqm_mul(xm, xm));
-            yhi[j] = fqm_mul(yhi[j - (1 << t)], cs[CS_YINVP(k) + LO + t]);
-        }
-    }
+    bpv_split_tables(cs, k, m);
 }
 
 // One lane per (proof, i): g_i : a s_i + z ; h_i : y^-i (b s_i^-1 - d_i) - z          :670-705
 // s_i = prod_t (bit_t(i) ? x_{k-1-t} : x_{k-1-t}^-1), s_i^-1 = s_{nm-1-i}; d_i = z^(2+i/n) 2^(i mod n).
+// Bulletproofs+ (wip != 0, range_proof_wip.rs:537-557) with the constants of k_wipv_consts:
+// G_i : (e r') s_i y^-i + e^2 z ; H_i : (e s') s_i^-1 - e^2 z - (e^2 y^nm z^(2(1+i/n))) 2^(i mod n) y^-i.
 __global__ __launch_bounds__(256) void k_bpv_vec(int n_bits, int m, int k, size_t nproofs, const fqm* __restrict__ cst, int c, int W,
-                                                 tdig_t* __restrict__ digF, fqm* __restrict__ scF, const int* __restrict__ bad) {
+                                                 tdig_t* __restrict__ digF, fqm* __restrict__ scF, const int* __restrict__ bad, int wip) {
     const int nm = n_bits * m;
     size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= nproofs * (size_t)nm) return;
@@ -467,12 +475,18 @@ __global__ __launch_bounds__(256) void k_bpv_vec(int n_bits, int m, int k, size_
     fqm sinv = fqm_mul(slo[lom - lo], shi[him - hi]);
     fqm yip = fqm_mul(cs[CS_YLO(k, m) + lo], cs[CS_YHI(k, m) + hi]);
     fqm z_m = cs[CS_Z];
-    fqm gs = fqm_add(fqm_mul(cs[CS_A], s), z_m);
     fq two_r = fq_zero();
     int r = i % n_bits;
     two_r.v[r >> 5] = 1u << (r & 31);
     fqm d_i = fqm_mul(fqm_from_fq(two_r), cs[CS_ZPOW(k) + i / n_bits]);
-    fqm hs = fqm_sub(fqm_mul(yip, fqm_sub(fqm_mul(cs[CS_B], sinv), d_i)), z_m);
+    fqm gs, hs;
+    if (wip) {
+        gs = fqm_add(fqm_mul(fqm_mul(cs[CS_A], s), yip), z_m);
+        hs = fqm_sub(fqm_sub(fqm_mul(cs[CS_B], sinv), z_m), fqm_mul(d_i, yip));
+    } else {
+        gs = fqm_add(fqm_mul(cs[CS_A], s), z_m);
+        hs = fqm_sub(fqm_mul(yip, fqm_sub(fqm_mul(cs[CS_B], sinv), d_i)), z_m);
+    }
     if (scF) {
         scF[pr * (size_t)(2 * nm + 2) + i] = gs;
         scF[pr * (size_t)(2 * nm + 2) + nm + i] = hs;
@@ -494,13 +508,203 @@ hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, i
     const int nm = n_bits * m;
     hipLaunchKernelGGL(k_bpv_hash1, dim3((unsigned)((nproofs * 4 + 63) / 64)), dim3(64), 0, st, proofs, proof_len, k, m, nm, nproofs, pts, gens,
                        chal, bad);
-    hipLaunchKernelGGL(k_bpv_fixmul, dim3((unsigned)((nproofs + 256 / (2 * FM_SUB) - 1) / (256 / (2 * FM_SUB)))), dim3(256), 0, st, k, nm, nproofs, table, c, W, chal, fixres, bad);
+    hipLaunchKernelGGL(k_bpv_fixmul, dim3((unsigned)((nproofs + 256 / (2 * FM_SUB) - 1) / (256 / (2 * FM_SUB)))), dim3(256), 0, st, k, nm, nproofs, table, c, W, chal, fixres, bad, 2);
     hipLaunchKernelGGL(k_bpv_fixinv, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, nproofs, fixres, fixaff, bad);
     hipLaunchKernelGGL(k_bpv_hash2, dim3((unsigned)((nproofs * (k + 1) + 63) / 64)), dim3(64), 0, st, k, m, nproofs, pts, fixaff, chal, bad);
     hipLaunchKernelGGL(k_bpv_consts, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W,
                        digF, scF, varS, reinterpret_cast<fqm*>(cst), bad);
     hipLaunchKernelGGL(k_bpv_vec, dim3((unsigned)((nproofs * (size_t)nm + 255) / 256)), dim3(256), 0, st, n_bits, m, k, nproofs,
-                       reinterpret_cast<const fqm*>(cst), c, W, digF, scF, bad);
+                       reinterpret_cast<const fqm*>(cst), c, W, digF, scF, bad, 0);
+    return hipGetLastError();
+}
+
+// ================================================================================================
+// Bulletproofs+ : scalar side of the batched `RangeProofWIP::aggregated_verify`
+// (/root/reference/src/proofs/range_proof_wip.rs:419-574).  Same kernel shapes as above:
+//   k_wipv_hash1  k+2 lanes/proof  y = H(A), e = H(a_tag, b_tag, g, h), x_j = H(L_j, R_j, g, h)   (:420, :465-467, :477)
+//   k_bpv_fixmul  (one multiplication per proof) y*G (:423);  k_wipv_fixinv -> affine
+//   k_wipv_hash2  1 lane/proof     z = H(A, yG)                                                 (:424)
+//   k_wipv_consts 1 lane/proof     one batched inversion for y, y-1, x_j; zeta; scalars of g, h, A, L_j, R_j, a_tag, V_j
+//   k_bpv_vec     (wip = 1)        G_i, H_i scalars -> signed window digits
+// Point order in `pts` (k_wipv_decompress): b_tag, A, L[k], R[k], a_tag, V[m]; the variable terms of the MSM are
+// pts[1 ..] in that order and the sum is compared with pts[0] = b_tag (:604).
+// proof byte layout (oracle/encoding.py): A | L[k] | R[k] | a_tag b_tag | r' s' delta'
+#define PFW_SCALARS(k) (33 * (2 * (k) + 3))
+#define CH_E CH_X
+
+__global__ __launch_bounds__(64) void k_wipv_hash1(const uint8_t* __restrict__ proofs, size_t proof_len, int k, int m, int nm, size_t nproofs,
+                                                   const affine_mem* __restrict__ pts, const affine_mem* __restrict__ gens, fq* __restrict__ chal,
+                                                   int* __restrict__ bad) {
+    __shared__ __align__(4) uint8_t lds[64 * MSG_STRIDE];
+    const int jobs = k + 2;
+    size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (gid >= nproofs * jobs) return;
+    size_t pr = gid / jobs;
+    int job = (int)(gid % jobs);
+    if (bad[pr]) return;
+    uint8_t* buf = lds + threadIdx.x * MSG_STRIDE;
+    const int NPT = 3 + 2 * k + m;
+    const affine_mem* P = pts + pr * NPT;
+    int pos = 0;
+    if (job == 0) {  // y = H(A)                                               range_proof_wip.rs:420
+        const uint8_t* sc = proofs + pr * proof_len + PFW_SCALARS(k);
+        // scalars in the proof must be canonical (< q), as curv's deserialisation yields
+        if (!(fq_be_is_canonical(sc) && fq_be_is_canonical(sc + 32) && fq_be_is_canonical(sc + 64))) atomicOr(&bad[pr], 1);
+        msg_put_point(buf, pos, P[1]);
+        chal[pr * CH_COUNT(k) + CH_Y] = msg_result_scalar(buf, pos);
+    } else if (job == 1) {  // e = H(a_tag, b_tag, g, h)                        :465-467
+        msg_put_point(buf, pos, P[2 + 2 * k]);
+        msg_put_point(buf, pos, P[0]);
+        msg_put_point(buf, pos, gens[2 * nm]);
+        msg_put_point(buf, pos, gens[2 * nm + 1]);
+        chal[pr * CH_COUNT(k) + CH_E] = msg_result_scalar(buf, pos);
+    } else {  // x_j = H(L_j, R_j, g, h)                                        :477
+        const int j = job - 2;
+        msg_put_point(buf, pos, P[2 + j]);
+        msg_put_point(buf, pos, P[2 + k + j]);
+        msg_put_point(buf, pos, gens[2 * nm]);
+        msg_put_point(buf, pos, gens[2 * nm + 1]);
+        chal[pr * CH_COUNT(k) + CH_XJ + j] = msg_result_scalar(buf, pos);
+    }
+}
+
+// affine yG; y = 0 makes it the identity (the reference panics at :458 mod_inv unwrap) -> malformed
+__global__ __launch_bounds__(64) void k_wipv_fixinv(size_t nproofs, const xyzz* __restrict__ fixres, affine_mem* __restrict__ fixaff,
+                                                    int* __restrict__ bad) {
+    size_t pr = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (pr >= nproofs || bad[pr]) return;
+    xyzz a = fixres[pr * 2];
+    if (xyzz_is_inf(a)) {
+        atomicOr(&bad[pr], 1);
+        return;
+    }
+    fixaff[pr * 2] = affine_store(xyzz_to_affine(a));
+}
+
+// z = H(A, yG)                                                                 :424
+__global__ __launch_bounds__(64) void k_wipv_hash2(int k, int m, size_t nproofs, const affine_mem* __restrict__ pts,
+                                                   const affine_mem* __restrict__ fixaff, fq* __restrict__ chal, const int* __restrict__ bad) {
+    __shared__ __align__(4) uint8_t lds[64 * MSG_STRIDE];
+    size_t pr = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (pr >= nproofs || bad[pr]) return;
+    uint8_t* buf = lds + threadIdx.x * MSG_STRIDE;
+    const int NPT = 3 + 2 * k + m;
+    int pos = 0;
+    msg_put_point(buf, pos, pts[pr * NPT + 1]);
+    msg_put_point(buf, pos, fixaff[pr * 2]);
+    chal[pr * CH_COUNT(k) + CH_Z] = msg_result_scalar(buf, pos);
+}
+
+__global__ __launch_bounds__(64) void k_wipv_consts(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
+                                                    const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF, fq* __restrict__ varS,
+                                                    fqm* __restrict__ cst, int* __restrict__ bad) {
+    size_t pr = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (pr >= nproofs || bad[pr]) return;
+    const int nm = n_bits * m;
+    const int NV = 2 + 2 * k + m;
+    const uint8_t* sc = proofs + pr * proof_len + PFW_SCALARS(k);
+    const fq* ch = chal + pr * CH_COUNT(k);
+    fqm* cs = cst + pr * CS_COUNT(k, m);
+    fq* vs = varS + pr * (size_t)NV;
+    const fqm ONE = fqm_one();
+
+    fq y = ch[CH_Y];
+    fqm y_m = fqm_from_fq(y), z_m = fqm_from_fq(ch[CH_Z]), e_m = fqm_from_fq(ch[CH_E]);
+    fqm r_m = fqm_from_fq(fq_from_be_reduce(sc)), s_m = fqm_from_fq(fq_from_be_reduce(sc + 32)), dl_m = fqm_from_fq(fq_from_be_reduce(sc + 64));
+    fqm esq = fqm_mul(e_m, e_m);
+    fqm mesq = fqm_neg(esq);
+
+    // batched inversion of (y, y - 1, x_0 .. x_{k-1}); a zero x_j / y is `.unwrap()` panicking (:458, :479)
+    fqm ym1 = fqm_sub(y_m, ONE);
+    const bool y_is_one = fqm_is_zero(ym1);
+    if (y_is_one) ym1 = ONE;
+    fqm pref[BPV_MAXK + 2];
+    fqm run = y_m;
+    pref[0] = run;
+    run = fqm_mul(run, ym1);
+    pref[1] = run;
+    bool zero_ch = fq_is_zero(y);
+    for (int j = 0; j < k; j++) {
+        fq xv = ch[CH_XJ + j];
+        zero_ch = zero_ch || fq_is_zero(xv);
+        fqm xm = fqm_from_fq(xv);
+        cs[CS_XJ + j] = xm;
+        run = fqm_mul(run, xm);
+        pref[2 + j] = run;
+    }
+    if (zero_ch) {
+        atomicOr(&bad[pr], 1);
+        return;
+    }
+    fqm inv = fqm_inv(run);
+    for (int j = k - 1; j >= 0; j--) {
+        fqm xm = cs[CS_XJ + j];
+        fqm xi = fqm_mul(inv, pref[1 + j]);
+        inv = fqm_mul(inv, xm);
+        cs[CS_XINV(k) + j] = xi;
+        vs[1 + j] = fqm_to_fq(fqm_mul(mesq, fqm_mul(xm, xm)));      // L_j : -e^2 x_j^2     :483-487, 560
+        vs[1 + k + j] = fqm_to_fq(fqm_mul(mesq, fqm_mul(xi, xi)));  // R_j : -e^2 x_j^-2    :484-492, 561
+    }
+    fqm ym1inv = fqm_mul(inv, pref[0]);
+    fqm yinv_m = fqm_mul(inv, ym1);
+    fqm yp = yinv_m, ynm = y_m;
+    for (int t = 0; t < k; t++) {
+        cs[CS_YINVP(k) + t] = yp;
+        yp = fqm_mul(yp, yp);
+        ynm = fqm_mul(ynm, ynm);
+    }
+    // sum_{i=1..nm} y^i = y (y^nm - 1)/(y - 1)   (nm if y == 1)                :523-531
+    fqm sum_y;
+    if (y_is_one) {
+        fq t = fq_zero();
+        t.v[0] = (uint32_t)nm;
+        sum_y = fqm_from_fq(t);
+    } else {
+        sum_y = fqm_mul(y_m, fqm_mul(fqm_sub(ynm, ONE), ym1inv));
+    }
+    const fqm ynm1 = fqm_mul(ynm, y_m);  // y^(nm+1)                            :521
+    const fqm esq_ynm = fqm_mul(esq, ynm), mesq_ynm1 = fqm_mul(mesq, ynm1);
+    // z^(2(j+1)); sum_d = (2^n - 1) sum_j z^(2(j+1))                          :441-455
+    fqm zsq = fqm_mul(z_m, z_m);
+    fqm zp = zsq, sum_z = fqm_zero();
+    for (int j = 0; j < m; j++) {
+        cs[CS_ZPOW(k) + j] = fqm_mul(esq_ynm, zp);                  // e^2 y^nm z^(2(j+1)): factor of d_i y^(nm-i) in H_i
+        sum_z = fqm_add(sum_z, zp);
+        vs[2 + 2 * k + j] = fqm_to_fq(fqm_mul(mesq_ynm1, zp));      // V_j : -e^2 y^(nm+1) z^(2(j+1))   :568-571
+        zp = fqm_mul(zp, zsq);
+    }
+    fq two_n = fq_zero();
+    for (int b = 0; b < n_bits; b++) two_n.v[b >> 5] |= 1u << (b & 31);
+    fqm sum_d = fqm_mul(fqm_from_fq(two_n), sum_z);
+    // zeta = (z - z^2) sum_y - z y^(nm+1) sum_d                                :522-531
+    fqm zeta = fqm_sub(fqm_mul(fqm_sub(z_m, zsq), sum_y), fqm_mul(fqm_mul(z_m, ynm1), sum_d));
+    // g : r' s' y - e^2 zeta ; h : delta'                                      :532-535, 598
+    fqm sG = fqm_sub(fqm_mul(fqm_mul(r_m, s_m), y_m), fqm_mul(esq, zeta));
+    tdig_t* dg = digF + pr * (size_t)(2 * nm + 2) * W;
+    store_digits(fqm_to_fq(sG), c, W, dg + (size_t)(2 * nm) * W);
+    store_digits(fqm_to_fq(dl_m), c, W, dg + (size_t)(2 * nm + 1) * W);
+    vs[0] = fqm_to_fq(mesq);                    // A (range proof) : -e^2     :564-565
+    vs[1 + 2 * k] = fqm_to_fq(fqm_neg(e_m));    // a_tag : -e                 :574
+    cs[CS_Z] = fqm_mul(esq, z_m);               // e^2 z                      :539
+    cs[CS_A] = fqm_mul(e_m, r_m);               // e r'                       :538
+    cs[CS_B] = fqm_mul(e_m, s_m);               // e s'                       :548
+    bpv_split_tables(cs, k, m);
+}
+
+hipError_t launch_wipv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
+                                       const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fq* varS, fq* chal, fq* cst,
+                                       xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st) {
+    const int nm = n_bits * m;
+    hipLaunchKernelGGL(k_wipv_hash1, dim3((unsigned)((nproofs * (k + 2) + 63) / 64)), dim3(64), 0, st, proofs, proof_len, k, m, nm, nproofs, pts,
+                       gens, chal, bad);
+    hipLaunchKernelGGL(k_bpv_fixmul, dim3((unsigned)((nproofs + 256 / (2 * FM_SUB) - 1) / (256 / (2 * FM_SUB)))), dim3(256), 0, st, k, nm, nproofs,
+                       table, c, W, chal, fixres, bad, 1);
+    hipLaunchKernelGGL(k_wipv_fixinv, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, nproofs, fixres, fixaff, bad);
+    hipLaunchKernelGGL(k_wipv_hash2, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, k, m, nproofs, pts, fixaff, chal, bad);
+    hipLaunchKernelGGL(k_wipv_consts, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W,
+                       digF, varS, reinterpret_cast<fqm*>(cst), bad);
+    hipLaunchKernelGGL(k_bpv_vec, dim3((unsigned)((nproofs * (size_t)nm + 255) / 256)), dim3(256), 0, st, n_bits, m, k, nproofs,
+                       reinterpret_cast<const fqm*>(cst), c, W, digF, (fqm*)nullptr, bad, 1);
     return hipGetLastError();
 }
 

@@ -199,6 +199,18 @@ int bp_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint
 int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proof, size_t proof_len, const uint8_t* coms_xy,
                          int mode, uint8_t* verdict);
 
+/* bp_wip_rangeproof_verify_batch — `RangeProofWIP::aggregated_verify` (range_proof_wip.rs:388-609) for nproofs
+ * independent Bulletproofs+ proofs that share the generators (bp_generate_bases kind 1): challenges y, z, e, x_j
+ * (:420-424, :465-467, :477), the scalar vector (:497-574) and the single 2nm+2k+m+4-term MSM with the
+ * comparison against b_tag (:598-604), all on the GPU.  Verdict codes as bp_rangeproof_verify_batch.
+ *   proofs : canonical encoding A | L_1..L_k | R_1..R_k | a_tag b_tag (33 B each) | r' s' delta' (32 B),
+ *            proof_len = 195 + 66*k. */
+int bp_wip_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
+                                   const uint8_t* coms_xy, size_t nproofs, uint8_t* verdicts);
+/* Same with DEVICE pointers; asynchronous on the context's stream until bp_ctx_sync. */
+int bp_wip_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
+                                          const void* d_coms_xy, size_t nproofs, void* d_verdicts);
+
 /* Bulletproofs+ : `RangeProofWIP::prove` (range_proof_wip.rs:101-274) with
  * `WeightedInnerProdArg::prove` (weighted_inner_product.rs:47-268); tape = alpha, then (d_L, d_R) per
  * round, then r, s, delta, eta (1 + 2 log2(nm) + 4 scalars).  Proof = 195 + 66 log2(nm) bytes.

@@ -156,3 +156,120 @@ def test_rlc_small_cases_all_shapes(ctx, idx):
         assert got == want
     finally:
         gens.close()
+
+
+# ---- Bulletproofs+ batch verification (bp_wip_rangeproof_verify_batch) ------------------------------
+def _plus_gens(ctx, n, m, window_bits=8):
+    g, h, G, H = bpa.generate_bases(1, bpa.KZEN_SEED, n, m)
+    return bpa.Gens(ctx, g, h, G, H, window_bits), G, H
+
+
+def _case_batch(case):
+    proofs = [bytes.fromhex(case["proof"])] + [bytes.fromhex(t["proof"]) for t in case["tampered"]]
+    coms = [b"".join(bytes.fromhex(c) for c in case["commitments"])] + [
+        b"".join(bytes.fromhex(c) for c in t["commitments"]) for t in case["tampered"]]
+    want = [VERDICT_CODE[case["verdict"]]] + [VERDICT_CODE[t["verdict"]] for t in case["tampered"]]
+    return proofs, coms, want
+
+
+@pytest.mark.parametrize("idx", range(4))
+@pytest.mark.parametrize("lanes", [0, 4, 16, 64])
+def test_bpplus_batch_cases_valid_and_tampered(ctx, idx, lanes):
+    """`RangeProofWIP::aggregated_verify` (range_proof_wip.rs:388-609) on the GPU for a batch: the golden proofs
+    (n*m = 8 .. 256) and their tampered variants get the oracle's verdicts, at every lanes-per-proof setting."""
+    from _golden import bpplus_cases
+    case = bpplus_cases()[idx]
+    n, m = case["n"], case["m"]
+    gens, _, _ = _plus_gens(ctx, n, m)
+    ctx.set_verify_lanes(lanes)
+    try:
+        proofs, coms, want = _case_batch(case)
+        # the same proofs several times over, so that one launch holds more than one workgroup's worth of lanes
+        reps = 5
+        got = ctx.wip_rangeproof_verify_batch(gens, n, m, b"".join(proofs) * reps, b"".join(coms) * reps)
+        assert got == want * reps, [t["name"] for t in case["tampered"]]
+    finally:
+        ctx.set_verify_lanes(0)
+        gens.close()
+
+
+def test_bpplus_batch_c4_n64_m64(ctx):
+    """BASELINE.json configs[3] shape (n=64, m=64: 8284-term MSM per proof) through the batch verifier."""
+    case = load("bpplus_c4_n64_m64.json")
+    gens, _, _ = _plus_gens(ctx, 64, 64, window_bits=0)
+    try:
+        proofs, coms, want = _case_batch(case)
+        assert ctx.wip_rangeproof_verify_batch(gens, 64, 64, b"".join(proofs), b"".join(coms)) == want
+    finally:
+        gens.close()
+
+
+def test_bpplus_batch_many_distinct_proofs(ctx, oracle_c):
+    """96 distinct n=64 m=1 Bulletproofs+ proofs (made by bp_wip_rangeproof_prove, whose bytes the protocol tests pin
+    to the oracle) with tampered, malformed and out-of-range ones in between: the batch verdicts equal the
+    single-proof `aggregated_verify` verdicts (bp_wip_rangeproof_verify mode 2) and the oracle's on a sample."""
+    import random
+    from oracle import tape
+    from oracle.range_proof_wip import StatementRP
+    from oracle import encoding
+    rng = random.Random(515)
+    n, m, k = 64, 1, 6
+    plen = 195 + 66 * k
+    gens, G, H = _plus_gens(ctx, n, m, window_bits=10)
+    Gp, Hp = ec.dec64(G), ec.dec64(H)
+    try:
+        proofs, coms, kinds = [], [], []
+        for i in range(96):
+            tb = tape.make_tape_bytes("plusbatch%d" % i, m + 1 + 2 * k + 4)
+            v = rng.randrange(1 << n) if i % 11 != 7 else (1 << n) + 5  # out of range: proof does not verify
+            r = int.from_bytes(tb[:32], "big")
+            com = ec.enc64(oracle_c.add(oracle_c.mul(Gp, v), oracle_c.mul(Hp, r)))
+            pf = bytearray(ctx.wip_rangeproof_prove(gens, n, v.to_bytes(32, "big"), tb[:32], tb[32:]))
+            kind = "ok" if i % 11 != 7 else "oor"
+            if i % 7 == 3:
+                pf[33 * (2 * k + 3) + 40] ^= 0x10  # s' bit
+                kind = "tampered"
+            elif i % 13 == 5:
+                pf[33 * 2 + 9] ^= 1  # L_1 x coordinate: another point or not a point at all
+                kind = "point"
+            elif i % 17 == 9:
+                pf[33 * (2 * k + 3):33 * (2 * k + 3) + 32] = b"\xff" * 32  # r' >= q: would not deserialize
+                kind = "scalar"
+            proofs.append(bytes(pf))
+            coms.append(com)
+            kinds.append(kind)
+        got = ctx.wip_rangeproof_verify_batch(gens, n, m, b"".join(proofs), b"".join(coms))
+        for i in range(96):
+            if kinds[i] == "ok":
+                assert got[i] == 0, i
+            elif kinds[i] in ("oor", "tampered"):
+                assert got[i] == 3, (i, kinds[i])
+            elif kinds[i] == "scalar":
+                assert got[i] == 255, i
+            else:
+                assert got[i] in (3, 255), i
+        # single-proof path on every well-formed one
+        for i in range(96):
+            if got[i] != 255:
+                assert ctx.wip_rangeproof_verify(gens, n, m, proofs[i], coms[i], 2) == got[i], (i, kinds[i])
+        # the oracle on a sample (one of each kind that deserializes)
+        stmt = StatementRP.generate_bases(curv.KZEN_SEED, m, n)
+        seen = set()
+        for i in range(96):
+            if kinds[i] in seen or got[i] == 255:
+                continue
+            seen.add(kinds[i])
+            pr = encoding.decode_bpplus(proofs[i])
+            assert VERDICT_CODE[pr.aggregated_verify(stmt, [ec.dec64(coms[i])])] == got[i], (i, kinds[i])
+    finally:
+        gens.close()
+
+
+def test_bpplus_batch_rejects_bad_sizes(ctx):
+    gens, _, _ = _plus_gens(ctx, 8, 1, window_bits=4)
+    try:
+        with pytest.raises(bpa.BpError) as e:
+            ctx.wip_rangeproof_verify_batch(gens, 16, 1, b"\0" * (195 + 66 * 4), b"\0" * 64)  # nm != gens nm
+        assert e.value.code == -1
+    finally:
+        gens.close()
