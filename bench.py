@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rlc-single", action="store_true", help="RLC side measurement with one context instead of two")
     ap.add_argument("--no-rlc", action="store_true", help="skip the random-linear-combination side measurement")
+    ap.add_argument("--no-bpplus", action="store_true", help="skip the Bulletproofs+ batch side measurement")
     ap.add_argument("--skip-check", action="store_true", help="timing experiments only: do not compare verdicts")
     ap.add_argument("--cpu-sample", type=int, default=1200, help="proofs verified by the CPU baseline")
     return ap.parse_args()
@@ -169,6 +170,8 @@ def bench_msm(args):
     if world == 1:
         import threading
         ctx_b = bpa.Context(local_rank)
+        ctx.set_msm_pipeline(1)  # several contexts in flight: one window group each (bp_msm_set_pipeline)
+        ctx_b.set_msm_pipeline(1)
         ctx_b.msm_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
         outs = [None, None]
 
@@ -396,6 +399,9 @@ def main():
         # the latency-bound tail of one batch's MSM overlaps the other batch's decompression / accumulation
         import threading
         ctx_b = bpa.Context(local_rank)
+        if not args.rlc_single:  # several contexts in flight: one window group per MSM (bp_msm_set_pipeline)
+            ctx.set_msm_pipeline(1)
+            ctx_b.set_msm_pipeline(1)
         d_v3 = torch.full((P,), 77, dtype=torch.uint8, device=dev)
         ctx_b.rangeproof_verify_batch_rlc_device(gens, 64, 1, d_valid.data_ptr(), plen, d_coms.data_ptr(), P, seed, d_v3.data_ptr())
         nthr = 1 if args.rlc_single else 2
@@ -416,6 +422,7 @@ def main():
         dt_rlc = time.perf_counter() - t0
         assert not bool(d_v2.any().item()) and not bool(d_v3.any().item())
         ctx_b.close()
+        ctx.set_msm_pipeline(0)
         if world > 1:
             t = torch.tensor([dt_rlc], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -423,6 +430,64 @@ def main():
         rlc = {"value": world * P * args.steps / dt_rlc, "unit": "proofs/s", "ms_per_step": dt_rlc / args.steps * 1e3, "contexts_in_flight": nthr,
                "what": "bp_rangeproof_verify_batch_rlc_device on the same batch with no tampered proof: one fixed-base MSM over the "
                        "generators + one %d-point Pippenger MSM per step; a failing batch falls back to the per-proof path" % (17 * P)}
+
+    # Bulletproofs+ side measurement (one GPU only): RangeProofWIP::aggregated_verify for the same number of n=64 m=1
+    # proofs per step through bp_wip_rangeproof_verify_batch_device.  64 distinct proofs made here by the GPU prover
+    # (bp_wip_rangeproof_prove, pinned to the oracle's bytes by tests/test_gpu_proto.py), tiled, 1/16 tampered.
+    plus = None
+    if world == 1 and not args.no_bpplus:
+        import hashlib
+        g2, h2, G2, H2 = ctx.generate_bases(1, bpa.KZEN_SEED, 64, 1)
+        gens2 = bpa.Gens(ctx, g2, h2, G2, H2, args.window_bits)
+        plen2 = 195 + 66 * 6
+
+        def sc(tag, i):
+            d = bytearray(hashlib.sha256(b"bpmsm-bench-plus-%s-%d" % (tag, i)).digest())
+            d[0] &= 0x7F
+            d[31] |= 1
+            return bytes(d)
+
+        distinct = 64
+        pfs, cms = [], []
+        for i in range(distinct):
+            v = hashlib.sha256(b"bpmsm-bench-plus-v-%d" % i).digest()[:8].rjust(32, b"\0")
+            r = sc(b"r", i)
+            tape = b"".join(sc(b"t%d" % i, j) for j in range(1 + 2 * 6 + 4))
+            cms.append(ctx.msm(G2 + H2, v + r, None))
+            pfs.append(ctx.wip_rangeproof_prove(gens2, 64, v, r, tape))
+        pb2 = bytearray(P * plen2)
+        cb2 = bytearray(P * 64)
+        want2 = bytearray(P)
+        for j in range(P):
+            i = j % distinct
+            pb2[j * plen2:(j + 1) * plen2] = pfs[i]
+            cb2[j * 64:(j + 1) * 64] = cms[i]
+            if j % 16 == 5:
+                pb2[j * plen2 + 33 * 15 + 64 + 31] ^= 1  # delta' bit
+                want2[j] = 3
+        d_p2 = torch.frombuffer(pb2, dtype=torch.uint8).to(dev)
+        d_c2 = torch.frombuffer(cb2, dtype=torch.uint8).to(dev)
+        d_v4 = torch.full((P,), 77, dtype=torch.uint8, device=dev)
+
+        def step2():
+            ctx.wip_rangeproof_verify_batch_device(gens2, 64, 1, d_p2.data_ptr(), plen2, d_c2.data_ptr(), P, d_v4.data_ptr())
+
+        for _ in range(max(1, args.warmup)):
+            step2()
+        ctx.sync()
+        if bytes(d_v4.cpu().numpy().tobytes()) != bytes(want2) and not args.skip_check:
+            raise SystemExit("Bulletproofs+ verdict mismatch")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step2()
+        ctx.sync()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        plus = {"value": P * args.steps / dt2, "unit": "proofs/s", "ms_per_step": dt2 / args.steps * 1e3, "msm_terms_per_proof": 146,
+                "what": "bp_wip_rangeproof_verify_batch_device: RangeProofWIP::aggregated_verify (Bulletproofs+) of %d independent n=64 m=1 "
+                        "proofs per step (64 distinct GPU-made proofs tiled, 1/16 tampered, verdicts checked)" % P}
+        gens2.close()
 
     if rank == 0:
         total_proofs = world * P * args.steps
@@ -448,6 +513,7 @@ def main():
                        "msm_mpts_per_s": value * 147 / 1e6},
             "kernel_ms": kms,
             "rlc_batch": rlc,
+            "bpplus_batch": plus,
             "roofline": {
                 "bound": "valu_int32_mad",
                 "kernel": "k_bpv_msm",

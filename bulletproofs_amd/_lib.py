@@ -18,6 +18,7 @@ EXPORTED_SYMBOLS = [
     "bp_msm_device",
     "bp_msm_set_window",
     "bp_msm_set_path",
+    "bp_msm_set_pipeline",
     "bp_proto_set_path",
     "bp_msm_batch",
     "bp_msm_auto_window",
@@ -90,6 +91,8 @@ def lib():
     L.bp_msm_set_window.restype = None
     L.bp_msm_set_path.argtypes = [vp, i32]
     L.bp_msm_set_path.restype = None
+    L.bp_msm_set_pipeline.argtypes = [vp, i32]
+    L.bp_msm_set_pipeline.restype = None
     L.bp_proto_set_path.argtypes = [vp, i32]
     L.bp_proto_set_path.restype = None
     L.bp_gens_create.argtypes = [vp, cp, cp, sz, cp, cp, i32, ctypes.POINTER(vp)]
@@ -198,6 +201,10 @@ class Context:
     def set_path(self, path):
         """0 = automatic, 1 = LDS slice path, 2 = global sorted path (testing / tuning)."""
         lib().bp_msm_set_path(self._h, path)
+
+    def set_msm_pipeline(self, mode):
+        """0 = window groups on side streams (lowest latency of one large MSM), 1 = one group (several contexts in flight)."""
+        lib().bp_msm_set_pipeline(self._h, mode)
 
     def set_proto_path(self, path):
         """0 = generator MSMs of prove/verify from the fixed-base table (default), 1 = reference-structured rounds."""

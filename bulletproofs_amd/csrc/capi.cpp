@@ -233,7 +233,7 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
         // multi-GPU partials)
         int gsz[SortedStreams::kMaxGroups];
         int ng = 0;
-        if (!want_c && n2 >= ((size_t)1 << 17)) ng = plan_window_groups(W, gsz);
+        if (!want_c && n2 >= ((size_t)1 << 17) && ctx->msm_pipeline == 0) ng = plan_window_groups(W, gsz);
         if (ng > 1 && !ctx->srt_streams) {
             SortedStreams* ss = new SortedStreams();
             memset(ss, 0, sizeof(*ss));
@@ -382,6 +382,9 @@ void bp_msm_set_window(bp_ctx* ctx, int c) {
 }
 void bp_msm_set_path(bp_ctx* ctx, int path) {
     if (ctx) ctx->msm_path = (path == 1 || path == 2) ? path : 0;
+}
+void bp_msm_set_pipeline(bp_ctx* ctx, int mode) {
+    if (ctx) ctx->msm_pipeline = mode == 1 ? 1 : 0;
 }
 void bp_proto_set_path(bp_ctx* ctx, int path) {
     if (ctx) ctx->proto_path = path == 1 ? 1 : 0;

@@ -39,6 +39,7 @@ struct bp_ctx {
     int* d_err = nullptr;
     int forced_c = 0;
     int msm_path = 0;  // 0 auto, 1 LDS slice path, 2 sorted path (bp_msm_set_path)
+    int msm_pipeline = 0;  // 0 = window groups on side streams (lowest latency of one call), 1 = one group (bp_msm_set_pipeline)
     int verify_lanes = 0;
     int proto_path = 0;  // protocol layer: 0 = every generator MSM from the fixed-base table, 1 = reference-structured (bp_proto_set_path)
     // optional per-kernel timing (bp_profile_*): HIP events on this context's stream

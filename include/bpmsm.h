@@ -85,6 +85,11 @@ void bp_msm_set_window(bp_ctx* ctx, int c);
 /* Testing / tuning knob: 0 = automatic, 1 = LDS slice path (small / medium n), 2 = global sorted
  * path (large n).  Both compute the same sum; results are identical. */
 void bp_msm_set_path(bp_ctx* ctx, int path);
+/* Large MSMs (>= 2^16 terms) run their windows in groups, each group's latency-bound tail (bucket reduction, Horner
+ * chain) on side streams beside the next group's accumulation: mode 0 (default), the lowest latency of ONE call.
+ * mode 1 = one group, no side streams: less total GPU work, the better choice when several contexts keep the GPU
+ * busy at once (their tails overlap each other anyway).  Results are identical. */
+void bp_msm_set_pipeline(bp_ctx* ctx, int mode);
 
 /* Testing / tuning knob for the protocol entry points (bp_rangeproof_prove / _verify, bp_wip_*):
  *   0 (default): every MSM over g_vec / h_vec / G / H is evaluated from the resident fixed-base table; the

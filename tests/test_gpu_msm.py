@@ -156,6 +156,11 @@ def test_msm_grouped_pipeline_skewed_scalars(ctx, oracle_c):
         want_scalar = sum(ks[i] * rs[idx[i]] for i in range(n)) % ec.Q
         want = ec.enc64(oracle_c.mul(ec.G, want_scalar)) if want_scalar else bytes(64)
         assert ctx.msm(pb, sb, None) == want, name
+        ctx.set_msm_pipeline(1)  # one window group, no side streams (bp_msm_set_pipeline): same bytes
+        try:
+            assert ctx.msm(pb, sb, None) == want, name
+        finally:
+            ctx.set_msm_pipeline(0)
 
 
 def test_msm_full_size_2pow20(ctx, oracle_c):
