@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--rlc-single", action="store_true", help="RLC side measurement with one context instead of two")
     ap.add_argument("--no-rlc", action="store_true", help="skip the random-linear-combination side measurement")
     ap.add_argument("--no-bpplus", action="store_true", help="skip the Bulletproofs+ batch side measurement")
+    ap.add_argument("--no-c2", action="store_true", help="skip the n=64 m=16 batch side measurement")
     ap.add_argument("--skip-check", action="store_true", help="timing experiments only: do not compare verdicts")
     ap.add_argument("--cpu-sample", type=int, default=1200, help="proofs verified by the CPU baseline")
     return ap.parse_args()
@@ -431,52 +432,59 @@ def main():
                "what": "bp_rangeproof_verify_batch_rlc_device on the same batch with no tampered proof: one fixed-base MSM over the "
                        "generators + one %d-point Pippenger MSM per step; a failing batch falls back to the per-proof path" % (17 * P)}
 
-    # Bulletproofs+ side measurement (one GPU only): RangeProofWIP::aggregated_verify for the same number of n=64 m=1
-    # proofs per step through bp_wip_rangeproof_verify_batch_device.  64 distinct proofs made here by the GPU prover
-    # (bp_wip_rangeproof_prove, pinned to the oracle's bytes by tests/test_gpu_proto.py), tiled, 1/16 tampered.
-    plus = None
-    if world == 1 and not args.no_bpplus:
+    # Side measurements on one GPU (reported beside `value`, never as it), proofs made here by the GPU provers
+    # (bp_rangeproof_prove / bp_wip_rangeproof_prove, pinned to the oracle's bytes by tests/test_gpu_proto.py),
+    # tiled to the batch, 1/16 tampered, verdicts checked:
+    #   bpplus_batch  RangeProofWIP::aggregated_verify (Bulletproofs+), n=64 m=1, as many proofs per step as the headline
+    #   c2_batch      RangeProof::aggregated_verify at BASELINE.json configs[1]'s shape, n=64 m=16 (2089-term MSM per proof)
+    def side_batch(kind, m, P_side, distinct, what):
         import hashlib
-        g2, h2, G2, H2 = ctx.generate_bases(1, bpa.KZEN_SEED, 64, 1)
+        nm = 64 * m
+        k = nm.bit_length() - 1
+        g2, h2, G2, H2 = ctx.generate_bases(kind, bpa.KZEN_SEED, 64, m)
         gens2 = bpa.Gens(ctx, g2, h2, G2, H2, args.window_bits)
-        plen2 = 195 + 66 * 6
+        plen2 = (195 if kind else 292) + 66 * k
+        tamper_at = (33 * (2 * k + 3) + 64 + 31) if kind else (4 * 33 + 64 + 31)  # delta' / tx, last byte
+        ntape = (1 + 2 * k + 4) if kind else (2 + 2 * nm + 2)
+        tag = b"plus" if kind else b"bp"
 
-        def sc(tag, i):
-            d = bytearray(hashlib.sha256(b"bpmsm-bench-plus-%s-%d" % (tag, i)).digest())
+        def sc(t, i, j):
+            d = bytearray(hashlib.sha256(b"bpmsm-bench-%s-%s-%d-%d-%d" % (tag, t, m, i, j)).digest())
             d[0] &= 0x7F
             d[31] |= 1
             return bytes(d)
 
-        distinct = 64
+        prove = ctx.wip_rangeproof_prove if kind else ctx.rangeproof_prove
         pfs, cms = [], []
         for i in range(distinct):
-            v = hashlib.sha256(b"bpmsm-bench-plus-v-%d" % i).digest()[:8].rjust(32, b"\0")
-            r = sc(b"r", i)
-            tape = b"".join(sc(b"t%d" % i, j) for j in range(1 + 2 * 6 + 4))
-            cms.append(ctx.msm(G2 + H2, v + r, None))
-            pfs.append(ctx.wip_rangeproof_prove(gens2, 64, v, r, tape))
-        pb2 = bytearray(P * plen2)
-        cb2 = bytearray(P * 64)
-        want2 = bytearray(P)
-        for j in range(P):
+            vs = [hashlib.sha256(b"bpmsm-bench-v-%d-%d" % (i, j)).digest()[:8].rjust(32, b"\0") for j in range(m)]
+            rs = [sc(b"r", i, j) for j in range(m)]
+            tape = b"".join(sc(b"t", i, j) for j in range(ntape))
+            cms.append(b"".join(ctx.msm(G2 + H2, vs[j] + rs[j], None) for j in range(m)))
+            pfs.append(prove(gens2, 64, b"".join(vs), b"".join(rs), tape))
+        pb2 = bytearray(P_side * plen2)
+        cb2 = bytearray(P_side * 64 * m)
+        want2 = bytearray(P_side)
+        for j in range(P_side):
             i = j % distinct
             pb2[j * plen2:(j + 1) * plen2] = pfs[i]
-            cb2[j * 64:(j + 1) * 64] = cms[i]
+            cb2[j * 64 * m:(j + 1) * 64 * m] = cms[i]
             if j % 16 == 5:
-                pb2[j * plen2 + 33 * 15 + 64 + 31] ^= 1  # delta' bit
+                pb2[j * plen2 + tamper_at] ^= 1
                 want2[j] = 3
         d_p2 = torch.frombuffer(pb2, dtype=torch.uint8).to(dev)
         d_c2 = torch.frombuffer(cb2, dtype=torch.uint8).to(dev)
-        d_v4 = torch.full((P,), 77, dtype=torch.uint8, device=dev)
+        d_v4 = torch.full((P_side,), 77, dtype=torch.uint8, device=dev)
+        fn = ctx.wip_rangeproof_verify_batch_device if kind else ctx.rangeproof_verify_batch_device
 
         def step2():
-            ctx.wip_rangeproof_verify_batch_device(gens2, 64, 1, d_p2.data_ptr(), plen2, d_c2.data_ptr(), P, d_v4.data_ptr())
+            fn(gens2, 64, m, d_p2.data_ptr(), plen2, d_c2.data_ptr(), P_side, d_v4.data_ptr())
 
         for _ in range(max(1, args.warmup)):
             step2()
         ctx.sync()
         if bytes(d_v4.cpu().numpy().tobytes()) != bytes(want2) and not args.skip_check:
-            raise SystemExit("Bulletproofs+ verdict mismatch")
+            raise SystemExit("side measurement: verdict mismatch (%s)" % what)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -484,10 +492,19 @@ def main():
         ctx.sync()
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t0
-        plus = {"value": P * args.steps / dt2, "unit": "proofs/s", "ms_per_step": dt2 / args.steps * 1e3, "msm_terms_per_proof": 146,
-                "what": "bp_wip_rangeproof_verify_batch_device: RangeProofWIP::aggregated_verify (Bulletproofs+) of %d independent n=64 m=1 "
-                        "proofs per step (64 distinct GPU-made proofs tiled, 1/16 tampered, verdicts checked)" % P}
+        nterms = 2 * nm + 2 * k + m + 5 if not kind else 2 * nm + 2 * k + m + 4
+        res = {"value": P_side * args.steps / dt2, "unit": "proofs/s", "ms_per_step": dt2 / args.steps * 1e3, "proofs_per_step": P_side,
+               "msm_terms_per_proof": nterms, "msm_mpts_per_s": P_side * args.steps / dt2 * nterms / 1e6, "table_bytes": gens2.table_bytes,
+               "what": what + " (%d distinct GPU-made proofs tiled, 1/16 tampered, verdicts checked)" % distinct}
         gens2.close()
+        return res
+
+    plus = c2 = None
+    if world == 1 and not args.no_bpplus:
+        plus = side_batch(1, 1, P, 64, "bp_wip_rangeproof_verify_batch_device: RangeProofWIP::aggregated_verify (Bulletproofs+), n=64 m=1")
+    if world == 1 and not args.no_c2:
+        c2 = side_batch(0, 16, max(256, P // 16), 16, "bp_rangeproof_verify_batch_device at BASELINE.json configs[1]'s shape: "
+                        "RangeProof::aggregated_verify, n=64 m=16")
 
     if rank == 0:
         total_proofs = world * P * args.steps
@@ -514,6 +531,7 @@ def main():
             "kernel_ms": kms,
             "rlc_batch": rlc,
             "bpplus_batch": plus,
+            "c2_batch": c2,
             "roofline": {
                 "bound": "valu_int32_mad",
                 "kernel": "k_bpv_msm",

@@ -265,7 +265,13 @@ static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bi
     // lanes per proof: fewer lanes share more doubling chains (less work) but need more proofs in
     // flight to fill 256 CUs x 4 SIMDs x 2 waves
     int tp = ctx->verify_lanes;
-    if (tp != 2 && tp != 4 && tp != 8 && tp != 16 && tp != 32 && tp != 64) tp = nproofs >= 65536 ? 2 : (nproofs >= 32768 ? 4 : (nproofs >= 12288 ? 8 : 16));
+    if (tp != 2 && tp != 4 && tp != 8 && tp != 16 && tp != 32 && tp != 64) {
+        tp = nproofs >= 65536 ? 2 : (nproofs >= 32768 ? 4 : (nproofs >= 12288 ? 8 : 16));
+        // aggregated proofs (n*m >= 512): the table part dominates and has no per-lane overhead, so take enough
+        // lanes for two waves per SIMD (131072 lanes) even with few proofs in the batch
+        if ((size_t)n_bits * m >= 512)
+            while (tp < 64 && nproofs * (size_t)tp < 131072) tp *= 2;
+    }
     if ((rc = ctx->vartab.reserve(bpv_msm_vartab_bytes(tp, nproofs))) != BP_OK) return rc;
     HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_table, gens->c, gens->W, (const tdig_t*)b_dig.p,
                           (const fq*)b_var.p, (xyzz*)ctx->vartab.p, (const int*)b_bad.p, (uint8_t*)d_verdicts, st, wip),

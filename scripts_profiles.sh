@@ -5,9 +5,9 @@ O=gpurun_out/prof; rm -rf $O; mkdir -p $O
 set -e
 timeout -k 10 300 python3 bench.py > $O/bench.json 2> $O/bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt.err
-timeout -s KILL 200 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $O/pmc_rd -o pmc -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/pmc_rd.json 2> $O/pmc_rd.err
-timeout -s KILL 200 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d $O/pmc_wr -o pmc -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/pmc_wr.json 2> $O/pmc_wr.err
-timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE -d $O/pmc_valu -o pmc -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/pmc_valu.json 2> $O/pmc_valu.err
+timeout -s KILL 200 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $O/pmc_rd -o pmc -- python3 bench.py --no-cpu-baseline --no-rlc --no-bpplus --no-c2 --steps 3 --warmup 1 > $O/pmc_rd.json 2> $O/pmc_rd.err
+timeout -s KILL 200 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d $O/pmc_wr -o pmc -- python3 bench.py --no-cpu-baseline --no-rlc --no-bpplus --no-c2 --steps 3 --warmup 1 > $O/pmc_wr.json 2> $O/pmc_wr.err
+timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE -d $O/pmc_valu -o pmc -- python3 bench.py --no-cpu-baseline --no-rlc --no-bpplus --no-c2 --steps 3 --warmup 1 > $O/pmc_valu.json 2> $O/pmc_valu.err
 timeout -k 10 300 python3 bench.py --workload msm > $O/msm_bench.json 2> $O/msm.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/msm_kt -o kt -- python3 bench.py --workload msm --steps 5 --warmup 2 > $O/msm_under_rocprof.json 2> $O/msm_kt.err
 timeout -k 10 300 python3 bench.py --workload msm --msm-log2 22 --steps 5 > $O/msm_bench_2p22.json 2>> $O/msm.err
