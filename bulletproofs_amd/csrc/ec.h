@@ -235,6 +235,19 @@ BP_HD affine xyzz_to_affine(const xyzz& p) {
     return r;
 }
 
+// The same with the variable-time inversion (fp_inv_var): for the single-lane tail of an MSM, where the
+// inversion's latency is exposed; throughput kernels keep xyzz_to_affine (uniform control flow).
+BP_HD affine xyzz_to_affine_var(const xyzz& p) {
+    if (xyzz_is_inf(p)) return affine_inf();
+    fp zi3 = fp_inv_var(p.ZZZ);
+    fp zi = fp_mul(p.ZZ, zi3);
+    fp zi2 = fp_sqr(zi);
+    affine r;
+    r.x = fp_mul(p.X, zi2);
+    r.y = fp_mul(p.Y, zi3);
+    return r;
+}
+
 // y^2 == x^3 + 7 ?
 BP_HD bool affine_on_curve(const affine& p) {
     fp rhs = fp_mul(fp_sqr(p.x), p.x);

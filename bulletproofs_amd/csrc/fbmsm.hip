@@ -80,7 +80,7 @@ __global__ __launch_bounds__(FB_T) void k_fb_final(const xyzz* __restrict__ part
         xyzz_add(acc, o);
     }
     xyzz s = fb_block_sum(acc, red, tid);
-    if (tid == 0) affine_to_be64(out_be + 64 * (size_t)job, xyzz_to_affine(s));
+    if (tid == 0) affine_to_be64(out_be + 64 * (size_t)job, xyzz_to_affine_var(s));
 }
 
 size_t fb_vartab_bytes(size_t njobs, int nxblk) { return njobs * (size_t)nxblk * FB_T * ECMUL_NT * sizeof(xyzz); }

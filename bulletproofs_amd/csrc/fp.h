@@ -357,4 +357,184 @@ BP_HD fp fp_from_be(const uint8_t* b) { return fp_from_words(fp_words_from_be(b)
 BP_HD void fp_to_be(uint8_t* b, const fp& a) { fp_words_to_be(b, fp_to_words(a)); }
 BP_HD bool fp_be_is_canonical(const uint8_t* b) { return fp_words_is_canonical(fp_words_from_be(b)); }
 
+// ---- fp_inv_var: inversion by Bernstein-Yang division steps ("safegcd"), variable time ----------------
+// For the single-lane tails (the last step of every MSM, one per call): a lone wave pays ~0.35 us per dependent
+// field multiplication, so Fermat's 270 of them are ~90 us; 18-25 rounds of 30 division steps on 30-bit signed limbs
+// are a third of that.  NOT for the throughput kernels: iteration counts and branches differ per lane, and a
+// wavefront pays for the union (those keep fp_inv).
+// Invariants (Bernstein, Yang: "Fast constant-time gcd computation and modular inversion", 2019; the limb layout and
+// the d/e update follow the published 32-bit formulation used by libsecp256k1's modinv32): f odd, f = d*x, g = e*x
+// (mod p), starting from f = p, g = x, d = 0, e = 1; divstep(delta, f, g) = (1 - delta, g, (g - f)/2) if delta > 0 and
+// g odd, else (1 + delta, f, (g + (g mod 2) f)/2).  When g reaches 0, f = +-1 and x^-1 = +-d.
+struct fp_s30 {
+    int32_t v[9];  // value = sum v[i] 2^(30 i); v[0..7] in [0, 2^30) once propagated, v[8] carries the sign
+};
+
+// 30 division steps on the low words; t = (u, v, q, r) with 2^30 f' = u f + v g, 2^30 g' = q f + r g.
+BP_HD int fp_divsteps30(int delta, uint32_t f, uint32_t g, int32_t t[4]) {
+    int32_t u = 1, v = 0, q = 0, r = 1;
+    for (int i = 0; i < 30; i++) {
+        if (g & 1u) {
+            if (delta > 0) {
+                delta = 1 - delta;
+                const uint32_t nf = g;
+                g = (g - f) >> 1;
+                f = nf;
+                const int32_t nu = q * 2, nv = r * 2;
+                q = q - u;
+                r = r - v;
+                u = nu;
+                v = nv;
+            } else {
+                delta = 1 + delta;
+                g = (g + f) >> 1;
+                q = q + u;
+                r = r + v;
+                u *= 2;
+                v *= 2;
+            }
+        } else {
+            delta = 1 + delta;
+            g >>= 1;
+            u *= 2;
+            v *= 2;
+        }
+    }
+    t[0] = u;
+    t[1] = v;
+    t[2] = q;
+    t[3] = r;
+    return delta;
+}
+
+BP_HD void fp_s30_update_fg(fp_s30& f, fp_s30& g, const int32_t t[4]) {
+    const int64_t u = t[0], v = t[1], q = t[2], r = t[3];
+    int64_t cf = u * f.v[0] + v * g.v[0];
+    int64_t cg = q * f.v[0] + r * g.v[0];
+    cf >>= 30;  // the low 30 bits are zero by construction
+    cg >>= 30;
+#pragma unroll
+    for (int i = 1; i < 9; i++) {
+        const int64_t fi = f.v[i], gi = g.v[i];
+        cf += u * fi + v * gi;
+        cg += q * fi + r * gi;
+        f.v[i - 1] = (int32_t)(cf & 0x3fffffff);
+        g.v[i - 1] = (int32_t)(cg & 0x3fffffff);
+        cf >>= 30;
+        cg >>= 30;
+    }
+    f.v[8] = (int32_t)cf;
+    g.v[8] = (int32_t)cg;
+}
+
+BP_HD int32_t fp_s30_p(int i) {  // p = 2^256 - 2^32 - 977 in 30-bit limbs
+    return i == 0 ? 0x3ffffc2f : (i == 1 ? 0x3ffffffb : (i < 8 ? 0x3fffffff : 0xffff));
+}
+
+// (d, e) <- (u d + v e, q d + r e) / 2^30 mod p, kept in (-2p, p)
+BP_HD void fp_s30_update_de(fp_s30& d, fp_s30& e, const int32_t t[4]) {
+    const uint32_t P_INV30 = 0x2ddacacfu;  // p^-1 mod 2^30
+    const int32_t u = t[0], v = t[1], q = t[2], r = t[3];
+    const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
+    int32_t md = (u & sd) + (v & se);
+    int32_t me = (q & sd) + (r & se);
+    int64_t cd = (int64_t)u * d.v[0] + (int64_t)v * e.v[0];
+    int64_t ce = (int64_t)q * d.v[0] + (int64_t)r * e.v[0];
+    md -= (int32_t)((P_INV30 * (uint32_t)cd + (uint32_t)md) & 0x3fffffffu);
+    me -= (int32_t)((P_INV30 * (uint32_t)ce + (uint32_t)me) & 0x3fffffffu);
+    cd += (int64_t)fp_s30_p(0) * md;
+    ce += (int64_t)fp_s30_p(0) * me;
+    cd >>= 30;
+    ce >>= 30;
+#pragma unroll
+    for (int i = 1; i < 9; i++) {
+        const int64_t di = d.v[i], ei = e.v[i];
+        cd += (int64_t)u * di + (int64_t)v * ei + (int64_t)fp_s30_p(i) * md;
+        ce += (int64_t)q * di + (int64_t)r * ei + (int64_t)fp_s30_p(i) * me;
+        d.v[i - 1] = (int32_t)(cd & 0x3fffffff);
+        e.v[i - 1] = (int32_t)(ce & 0x3fffffff);
+        cd >>= 30;
+        ce >>= 30;
+    }
+    d.v[8] = (int32_t)cd;
+    e.v[8] = (int32_t)ce;
+}
+
+BP_HD fp fp_inv_var(const fp& a) {
+    const fp_words aw = fp_to_words(a);  // canonical value in [0, p)
+    fp_s30 f, g, d, e;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        f.v[i] = fp_s30_p(i);
+        d.v[i] = 0;
+        e.v[i] = 0;
+        // bits [30 i, 30 i + 30) of the 256-bit value
+        const int bit = 30 * i, w = bit >> 5, sh = bit & 31;
+        uint64_t two = aw.w[w];
+        if (w + 1 < 8) two |= (uint64_t)aw.w[w + 1] << 32;
+        g.v[i] = (int32_t)((uint32_t)(two >> sh) & 0x3fffffffu);
+    }
+    e.v[0] = 1;
+    int delta = 1;
+    // at most 741 division steps are needed for 256-bit inputs (25 rounds); the bound below is only a guard
+    for (int it = 0; it < 40; it++) {
+        int32_t gz = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) gz |= g.v[i];
+        if (gz == 0) break;
+        int32_t t[4];
+        delta = fp_divsteps30(delta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+        fp_s30_update_de(d, e, t);
+        fp_s30_update_fg(f, g, t);
+    }
+    // f = +-1: x^-1 = f * d.  Normalise d from (-2p, p) to [0, p).
+    const bool neg = f.v[8] < 0;
+    int64_t c = 0;
+    int32_t o[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        c += neg ? -(int64_t)d.v[i] : (int64_t)d.v[i];
+        if (i < 8) {
+            o[i] = (int32_t)(c & 0x3fffffff);
+            c >>= 30;
+        } else {
+            o[8] = (int32_t)c;  // the top limb keeps the sign
+        }
+    }
+    for (int pass = 0; pass < 3; pass++) {  // value in (-2p, 2p): add or subtract p until it is in [0, p)
+        const bool isneg = o[8] < 0;
+        bool ge = !isneg;  // compare with p from the top limb down
+        if (ge) {
+            for (int i = 8; i >= 0; i--) {
+                if (o[i] != fp_s30_p(i)) {
+                    ge = o[i] > fp_s30_p(i);
+                    break;
+                }
+            }
+        }
+        if (!isneg && !ge) break;
+        int64_t cc = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            cc += (int64_t)o[i] + (isneg ? (int64_t)fp_s30_p(i) : -(int64_t)fp_s30_p(i));
+            if (i < 8) {
+                o[i] = (int32_t)(cc & 0x3fffffff);
+                cc >>= 30;
+            } else {
+                o[8] = (int32_t)cc;
+            }
+        }
+    }
+    fp_words rw;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        // word k = bits [32 k, 32 k + 32) from the 30-bit limbs
+        const int bit = 32 * k, l = bit / 30, sh = bit % 30;
+        uint64_t acc = (uint64_t)(uint32_t)o[l] >> sh;
+        acc |= (uint64_t)(uint32_t)o[l + 1] << (30 - sh);  // sh <= 14: two limbs cover the word
+        rw.w[k] = (uint32_t)acc;
+    }
+    return fp_from_words(rw);
+}
+
 }  // namespace bp

@@ -18,6 +18,7 @@ void bpt_fp_sqr(uint8_t* out, const uint8_t* a) { fp_to_be(out, fp_sqr(fp_from_b
 void bpt_fp_add(uint8_t* out, const uint8_t* a, const uint8_t* b) { fp_to_be(out, fp_add(fp_from_be(a), fp_from_be(b))); }
 void bpt_fp_sub(uint8_t* out, const uint8_t* a, const uint8_t* b) { fp_to_be(out, fp_sub(fp_from_be(a), fp_from_be(b))); }
 void bpt_fp_inv(uint8_t* out, const uint8_t* a) { fp_to_be(out, fp_inv(fp_from_be(a))); }
+void bpt_fp_inv_var(uint8_t* out, const uint8_t* a) { fp_to_be(out, fp_inv_var(fp_from_be(a))); }
 void bpt_fp_sqrt(uint8_t* out, const uint8_t* a) { fp_to_be(out, fp_sqrt_candidate(fp_from_be(a))); }
 
 static fq fq_from_be_raw(const uint8_t* b) { return fq_from_be_reduce(b); }

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64) void k_msm_horner(const xyzz* __restrict__ wsum
         xyzz_add(acc, o);
     }
     if (init) xyzz_madd(acc, affine_load(*init));
-    affine_mem m = affine_store(xyzz_to_affine(acc));
+    affine_mem m = affine_store(xyzz_to_affine_var(acc));
     if (out_limbs) *out_limbs = m;
     if (out_be) {
         uint32_t* dst = reinterpret_cast<uint32_t*>(out_be);

@@ -54,6 +54,22 @@ def test_fp(L):
         assert call1(L.bpt_fp_sqrt, a) == pow(a, (P + 1) // 4, P)
 
 
+def test_fp_inv_var(L):
+    """fp_inv_var (Bernstein-Yang division steps, used by the single-lane tails of every MSM) against Python's pow and
+    the Fermat chain: edge values, sparse values, small values, values near p, 20000 random ones."""
+    rng = random.Random(70)
+    vals = [0, 1, 2, 3, P - 1, P - 2, P - 3, 2**32, 2**32 + 977, 2**32 + 976, 2**255, P - 2**32 - 977, (1 << 224) - 1, P - 977, 2**30, 2**30 - 1,
+            2**60, 2**240, 2**240 - 1, (P + 1) // 2, (P - 1) // 2]
+    vals += [1 << k for k in range(0, 256, 7)] + [P - (1 << k) for k in range(0, 250, 11)]
+    vals += [rng.randrange(1 << k) for k in range(1, 256, 3)]
+    vals += [rng.randrange(P) for _ in range(20000)]
+    for a in vals:
+        want = pow(a, -1, P) if a else 0
+        assert call1(L.bpt_fp_inv_var, a) == want, hex(a)
+    for a in vals[:60]:
+        assert call1(L.bpt_fp_inv_var, a) == call1(L.bpt_fp_inv, a)
+
+
 def test_fq(L):
     rng = random.Random(8)
     edge = [0, 1, 2, Q - 1, Q - 2, 2**255, 2**128]
