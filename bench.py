@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-rlc", action="store_true", help="skip the random-linear-combination side measurement")
     ap.add_argument("--no-bpplus", action="store_true", help="skip the Bulletproofs+ batch side measurement")
     ap.add_argument("--no-c2", action="store_true", help="skip the n=64 m=16 batch side measurement")
+    ap.add_argument("--prove-threads", type=int, default=8, help="--workload prove: contexts in flight for the throughput figure")
     ap.add_argument("--skip-check", action="store_true", help="timing experiments only: do not compare verdicts")
     ap.add_argument("--cpu-sample", type=int, default=1200, help="proofs verified by the CPU baseline")
     return ap.parse_args()
@@ -255,6 +256,34 @@ def bench_prove(args):
             t, v = timeit(lambda: verify(gens, n, m, proof, coms, mode), reps)
             assert v == 0
             row[label] = t
+        # throughput with several contexts in flight (the library's threading model: one bp_ctx per host thread, bp_gens
+        # shared): the per-round host work and round trips of one proof overlap the GPU work of the others
+        import threading
+        nthr = args.prove_threads
+        if nthr > 1:
+            ctxs = [bpa.Context(int(os.environ.get("LOCAL_RANK", "0"))) for _ in range(nthr)]
+            per = max(2, reps)
+            bad = []
+
+            def worker(c):
+                for _ in range(per):
+                    if prove(gens, n, sec, bl, tape) != proof if c is ctx else (c.wip_rangeproof_prove if kind else c.rangeproof_prove)(
+                            gens, n, sec, bl, tape) != proof:
+                        bad.append(1)
+
+            for c in ctxs:  # warm-up: workspace allocation
+                (c.wip_rangeproof_prove if kind else c.rangeproof_prove)(gens, n, sec, bl, tape)
+            thr = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
+            t0 = time.perf_counter()
+            for t in thr:
+                t.start()
+            for t in thr:
+                t.join()
+            dtp = time.perf_counter() - t0
+            assert not bad, "a concurrent prove produced different bytes"
+            row["prove_per_s_%d_contexts" % nthr] = nthr * per / dtp
+            for c in ctxs:
+                c.close()
         rows.append(row)
         gens.close()
     out = {"metric": "single-proof latency (ms), secp256k1 range proofs through the C ABI", "unit": "ms", "n_gpus": 1,
