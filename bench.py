@@ -521,10 +521,29 @@ def main():
         ctx.sync()
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t0
+        rlc2 = None
+        if kind:  # the same batch without the tampered proofs through the random-linear-combination check, one context
+            for j in range(P_side):
+                if want2[j]:
+                    pb2[j * plen2 + tamper_at] ^= 1
+            d_pv = torch.frombuffer(pb2, dtype=torch.uint8).to(dev)
+            seed2 = bytes((11 * i + 3) & 255 for i in range(32))
+            fbk = ctx.wip_rangeproof_verify_batch_rlc_device(gens2, 64, m, d_pv.data_ptr(), plen2, d_c2.data_ptr(), P_side, seed2, d_v4.data_ptr())
+            assert not fbk and not bool(d_v4.any().item()), "BP+ rlc: all-valid batch must pass the combined check"
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                ctx.wip_rangeproof_verify_batch_rlc_device(gens2, 64, m, d_pv.data_ptr(), plen2, d_c2.data_ptr(), P_side, seed2, d_v4.data_ptr())
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t0
+            rlc2 = {"value": P_side * args.steps / dt3, "unit": "proofs/s", "ms_per_step": dt3 / args.steps * 1e3, "contexts_in_flight": 1,
+                    "what": "bp_wip_rangeproof_verify_batch_rlc_device on the all-valid version of the batch"}
         nterms = 2 * nm + 2 * k + m + 5 if not kind else 2 * nm + 2 * k + m + 4
         res = {"value": P_side * args.steps / dt2, "unit": "proofs/s", "ms_per_step": dt2 / args.steps * 1e3, "proofs_per_step": P_side,
                "msm_terms_per_proof": nterms, "msm_mpts_per_s": P_side * args.steps / dt2 * nterms / 1e6, "table_bytes": gens2.table_bytes,
                "what": what + " (%d distinct GPU-made proofs tiled, 1/16 tampered, verdicts checked)" % distinct}
+        if rlc2:
+            res["rlc"] = rlc2
         gens2.close()
         return res
 

@@ -34,6 +34,8 @@ EXPORTED_SYMBOLS = [
     "bp_rangeproof_verify_batch_rlc",
     "bp_wip_rangeproof_verify_batch",
     "bp_wip_rangeproof_verify_batch_device",
+    "bp_wip_rangeproof_verify_batch_rlc",
+    "bp_wip_rangeproof_verify_batch_rlc_device",
     "bp_rangeproof_verify_batch_rlc_device",
     "bp_ctx_sync",
     "bp_verify_set_lanes",
@@ -109,6 +111,10 @@ def lib():
     L.bp_wip_rangeproof_verify_batch.restype = i32
     L.bp_wip_rangeproof_verify_batch_device.argtypes = [vp, vp, i32, i32, vp, sz, vp, sz, vp]
     L.bp_wip_rangeproof_verify_batch_device.restype = i32
+    L.bp_wip_rangeproof_verify_batch_rlc.argtypes = [vp, vp, i32, i32, cp, sz, cp, sz, cp, cp, ctypes.POINTER(i32)]
+    L.bp_wip_rangeproof_verify_batch_rlc.restype = i32
+    L.bp_wip_rangeproof_verify_batch_rlc_device.argtypes = [vp, vp, i32, i32, vp, sz, vp, sz, cp, vp, ctypes.POINTER(i32)]
+    L.bp_wip_rangeproof_verify_batch_rlc_device.restype = i32
     L.bp_rangeproof_verify_batch_rlc.argtypes = [vp, vp, i32, i32, cp, sz, cp, sz, cp, cp, ctypes.POINTER(i32)]
     L.bp_rangeproof_verify_batch_rlc.restype = i32
     L.bp_rangeproof_verify_batch_rlc_device.argtypes = [vp, vp, i32, i32, vp, sz, vp, sz, cp, vp, ctypes.POINTER(i32)]
@@ -274,6 +280,27 @@ class Context:
         """Asynchronous device-pointer variant (ints); call sync() before reading verdicts."""
         _check(lib().bp_wip_rangeproof_verify_batch_device(self._h, gens._h, n_bits, m, ctypes.c_void_p(d_proofs), proof_len,
                                                            ctypes.c_void_p(d_coms), nproofs, ctypes.c_void_p(d_verdicts)))
+
+    def wip_rangeproof_verify_batch_rlc(self, gens, n_bits, m, proofs, coms_xy, seed):
+        """Bulletproofs+ verdicts through one random-linear-combination MSM -> (list of verdict codes, used_fallback)."""
+        proofs, coms_xy, seed = bytes(proofs), bytes(coms_xy), bytes(seed)
+        nm = n_bits * m
+        k = max(nm.bit_length() - 1, 0)
+        proof_len = 195 + 66 * k
+        nproofs = len(proofs) // proof_len if proof_len else 0
+        if nproofs * proof_len != len(proofs) or len(coms_xy) != nproofs * m * 64 or len(seed) != 32:
+            raise BpError(BP_EINVAL, "proofs/commitments/seed length mismatch")
+        out = ctypes.create_string_buffer(max(nproofs, 1))
+        fb = ctypes.c_int32(0)
+        _check(lib().bp_wip_rangeproof_verify_batch_rlc(self._h, gens._h, n_bits, m, proofs, proof_len, coms_xy, nproofs, seed, out,
+                                                        ctypes.byref(fb)))
+        return list(out.raw[:nproofs]), bool(fb.value)
+
+    def wip_rangeproof_verify_batch_rlc_device(self, gens, n_bits, m, d_proofs, proof_len, d_coms, nproofs, seed, d_verdicts):
+        fb = ctypes.c_int32(0)
+        _check(lib().bp_wip_rangeproof_verify_batch_rlc_device(self._h, gens._h, n_bits, m, d_proofs, proof_len, d_coms, nproofs, bytes(seed),
+                                                               d_verdicts, ctypes.byref(fb)))
+        return bool(fb.value)
 
     def rangeproof_verify_batch_rlc(self, gens, n_bits, m, proofs, coms_xy, seed):
         """Same verdicts through one random-linear-combination MSM (per-proof fallback when it fails)

@@ -50,9 +50,10 @@ __global__ void k_rlc_weights(const uint8_t* __restrict__ seed32, size_t nproofs
     rho[pr] = fqm_from_fq(r);
 }
 
+// Bulletproofs+ (wip): point order b_tag, A, L.., R.., a_tag, V.. (k_wipv_decompress), varS in the order of pts[1..]
 __global__ void k_rlc_var_scalars(int k, int m, size_t nproofs, const fqm* __restrict__ rho, const fq* __restrict__ varS,
-                                  uint8_t* __restrict__ sc_be) {
-    const int NPT = 4 + 2 * k + m, NV = 3 + 2 * k + m;
+                                  uint8_t* __restrict__ sc_be, int wip) {
+    const int NPT = (wip ? 3 : 4) + 2 * k + m, NV = (wip ? 2 : 3) + 2 * k + m;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= nproofs * (size_t)NPT) return;
     size_t pr = gid / NPT;
@@ -62,7 +63,9 @@ __global__ void k_rlc_var_scalars(int k, int m, size_t nproofs, const fqm* __res
     if (fqm_is_zero(r)) {
         out = fq_zero();
     } else if (j == 0) {
-        out = fqm_to_fq(fqm_neg(r));  // - rho_j A_j
+        out = fqm_to_fq(fqm_neg(r));  // - rho_j A_j  (Bulletproofs+: - rho_j b_tag_j)
+    } else if (wip) {
+        out = fqm_to_fq(fqm_mul(r, fqm_from_fq(varS[pr * (size_t)NV + (j - 1)])));
     } else {
         // point order A S T1 T2 L.. R.. V..  ->  varS order S, L.., R.., V.., T1, T2 (k_bpv_consts)
         int v = (j == 1) ? 0 : (j == 2) ? (1 + 2 * k + m) : (j == 3) ? (2 + 2 * k + m) : (j - 3);
@@ -115,9 +118,9 @@ hipError_t launch_rlc_weights(const uint8_t* seed32, size_t nproofs, const int* 
     hipLaunchKernelGGL(k_rlc_weights, dim3((unsigned)((nproofs + 255) / 256)), dim3(256), 0, st, seed32, nproofs, bad, rho);
     return hipGetLastError();
 }
-hipError_t launch_rlc_var_scalars(int k, int m, size_t nproofs, const fqm* rho, const fq* varS, uint8_t* sc_be, hipStream_t st) {
-    size_t total = nproofs * (size_t)(4 + 2 * k + m);
-    hipLaunchKernelGGL(k_rlc_var_scalars, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, k, m, nproofs, rho, varS, sc_be);
+hipError_t launch_rlc_var_scalars(int k, int m, size_t nproofs, const fqm* rho, const fq* varS, uint8_t* sc_be, hipStream_t st, int wip) {
+    size_t total = nproofs * (size_t)((wip ? 3 : 4) + 2 * k + m);
+    hipLaunchKernelGGL(k_rlc_var_scalars, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, k, m, nproofs, rho, varS, sc_be, wip);
     return hipGetLastError();
 }
 size_t rlc_colsum_chunks(size_t nproofs) { return (nproofs + RLC_CHUNK - 1) / RLC_CHUNK; }

@@ -253,8 +253,8 @@ static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bi
     prof_mark(ctx, 1);
     if (wip)
         HIPCHK(launch_wipv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
-                                           gens->d_table, gens->c, gens->W, (tdig_t*)b_dig.p, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
-                                           (int*)b_bad.p, st),
+                                           gens->d_table, gens->c, gens->W, (tdig_t*)b_dig.p, nullptr, (fq*)b_var.p, d_chal, d_cst, d_fixres,
+                                           d_fixaff, (int*)b_bad.p, st),
                "wipv_scalars");
     else
         HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
@@ -297,10 +297,11 @@ int bp_wip_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int 
 
 // Random-linear-combination batch verification (rlc_kernels.hip).  Synchronous: returns with the verdicts
 // written.  *used_fallback (nullable) = 1 when the combined check failed and the per-proof kernel decided.
-int bp_rangeproof_verify_batch_rlc_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
-                                          const void* d_coms_xy, size_t nproofs, const uint8_t seed[32], void* d_verdicts, int* used_fallback) {
+static int verify_batch_rlc_device_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
+                                        const void* d_coms_xy, size_t nproofs, const uint8_t seed[32], void* d_verdicts, int* used_fallback,
+                                        int wip) {
     int k = 0;
-    int rc = check_batch_args(ctx, gens, n_bits, m, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, &k);
+    int rc = check_batch_args(ctx, gens, n_bits, m, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, &k, wip);
     if (rc != BP_OK) return rc;
     if (!seed) return BP_EINVAL;
     if (used_fallback) *used_fallback = 0;
@@ -308,7 +309,7 @@ int bp_rangeproof_verify_batch_rlc_device(bp_ctx* ctx, const bp_gens* gens, int 
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = ctx->stream;
-    const int NPT = 4 + 2 * k + m, NV = 3 + 2 * k + m, np = gens->np, W = gens->W;
+    const int NPT = (wip ? 3 : 4) + 2 * k + m, NV = (wip ? 2 : 3) + 2 * k + m, np = gens->np, W = gens->W;
     if (nproofs * (size_t)NPT >= ((size_t)1 << 30)) {
         set_error_msg("rlc batch too large for one MSM");
         return BP_EINVAL;
@@ -349,14 +350,25 @@ int bp_rangeproof_verify_batch_rlc_device(bp_ctx* ctx, const bp_gens* gens, int 
     HIPCHK(hipMemcpyAsync(misc + o_gidx, h_idx.data(), ((size_t)np + 4) * 4, hipMemcpyHostToDevice, st), "memcpy index");
     HIPCHK(hipMemsetAsync(b_bad.p, 0, nproofs * sizeof(int), st), "memset");
     HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), st), "memset");
-    HIPCHK(launch_bpv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine_mem*)b_pts.p, (int*)b_bad.p, st),
-           "bpv_decompress");
-    HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
-                                      gens->d_table, gens->c, W, nullptr, (fqm*)b_scF.p, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
+    if (wip) {
+        HIPCHK(launch_wipv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine_mem*)b_pts.p,
                                       (int*)b_bad.p, st),
-           "bpv_scalars");
+               "wipv_decompress");
+        HIPCHK(launch_wipv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
+                                           gens->d_table, gens->c, W, nullptr, (fqm*)b_scF.p, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
+                                           (int*)b_bad.p, st),
+               "wipv_scalars");
+    } else {
+        HIPCHK(launch_bpv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine_mem*)b_pts.p,
+                                     (int*)b_bad.p, st),
+               "bpv_decompress");
+        HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
+                                          gens->d_table, gens->c, W, nullptr, (fqm*)b_scF.p, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
+                                          (int*)b_bad.p, st),
+               "bpv_scalars");
+    }
     HIPCHK(launch_rlc_weights(misc + o_seed, nproofs, (const int*)b_bad.p, (fqm*)b_rho.p, st), "rlc_weights");
-    HIPCHK(launch_rlc_var_scalars(k, m, nproofs, (const fqm*)b_rho.p, (const fq*)b_var.p, (uint8_t*)b_scbe.p, st), "rlc_var_scalars");
+    HIPCHK(launch_rlc_var_scalars(k, m, nproofs, (const fqm*)b_rho.p, (const fq*)b_var.p, (uint8_t*)b_scbe.p, st, wip), "rlc_var_scalars");
     HIPCHK(launch_rlc_colsum(np, nproofs, (const fqm*)b_rho.p, (const fqm*)b_scF.p, (const int*)b_bad.p, (fqm*)(misc + o_part), misc + o_fbe, st),
            "rlc_colsum");
     // the 2nm+2 generator terms: one fixed-base MSM from the table; its value is the init of the big MSM
@@ -377,9 +389,19 @@ int bp_rangeproof_verify_batch_rlc_device(bp_ctx* ctx, const bp_gens* gens, int 
     if (all_ok) return BP_OK;
     // some well-formed proof is invalid: the per-proof kernel decides (identical verdicts by construction)
     if (used_fallback) *used_fallback = 1;
-    if ((rc = verify_batch_device_nolock(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts)) != BP_OK) return rc;
+    if ((rc = verify_batch_device_nolock(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, wip)) != BP_OK) return rc;
     HIPCHK(hipStreamSynchronize(st), "sync");
     return BP_OK;
+}
+
+int bp_rangeproof_verify_batch_rlc_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
+                                          const void* d_coms_xy, size_t nproofs, const uint8_t seed[32], void* d_verdicts, int* used_fallback) {
+    return verify_batch_rlc_device_impl(ctx, gens, n_bits, m, d_proofs, proof_len, d_coms_xy, nproofs, seed, d_verdicts, used_fallback, 0);
+}
+int bp_wip_rangeproof_verify_batch_rlc_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
+                                              const void* d_coms_xy, size_t nproofs, const uint8_t seed[32], void* d_verdicts,
+                                              int* used_fallback) {
+    return verify_batch_rlc_device_impl(ctx, gens, n_bits, m, d_proofs, proof_len, d_coms_xy, nproofs, seed, d_verdicts, used_fallback, 1);
 }
 
 int bp_msm_batch(bp_ctx* ctx, const bp_gens* gens, const bp_msm_job* jobs, size_t njobs, uint8_t* out_xy) {
@@ -470,8 +492,18 @@ static int stage_batch(bp_ctx* ctx, const uint8_t* proofs, size_t proof_len, con
     return BP_OK;
 }
 
+static int verify_batch_rlc_host(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
+                                 const uint8_t* coms_xy, size_t nproofs, const uint8_t seed[32], uint8_t* verdicts, int* used_fallback, int wip);
 int bp_rangeproof_verify_batch_rlc(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
                                    const uint8_t* coms_xy, size_t nproofs, const uint8_t seed[32], uint8_t* verdicts, int* used_fallback) {
+    return verify_batch_rlc_host(ctx, gens, n_bits, m, proofs, proof_len, coms_xy, nproofs, seed, verdicts, used_fallback, 0);
+}
+int bp_wip_rangeproof_verify_batch_rlc(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
+                                       const uint8_t* coms_xy, size_t nproofs, const uint8_t seed[32], uint8_t* verdicts, int* used_fallback) {
+    return verify_batch_rlc_host(ctx, gens, n_bits, m, proofs, proof_len, coms_xy, nproofs, seed, verdicts, used_fallback, 1);
+}
+static int verify_batch_rlc_host(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
+                                 const uint8_t* coms_xy, size_t nproofs, const uint8_t seed[32], uint8_t* verdicts, int* used_fallback, int wip) {
     if (!ctx || !gens || m <= 0 || !seed) return BP_EINVAL;
     if (used_fallback) *used_fallback = 0;
     if (nproofs == 0) return BP_OK;
@@ -479,7 +511,7 @@ int bp_rangeproof_verify_batch_rlc(bp_ctx* ctx, const bp_gens* gens, int n_bits,
     void *d_p, *d_c, *d_v;
     int rc = stage_batch(ctx, proofs, proof_len, coms_xy, m, nproofs, &d_p, &d_c, &d_v);
     if (rc != BP_OK) return rc;
-    rc = bp_rangeproof_verify_batch_rlc_device(ctx, gens, n_bits, m, d_p, proof_len, d_c, nproofs, seed, d_v, used_fallback);
+    rc = verify_batch_rlc_device_impl(ctx, gens, n_bits, m, d_p, proof_len, d_c, nproofs, seed, d_v, used_fallback, wip);
     if (rc != BP_OK) return rc;
     std::vector<uint8_t> tmp(nproofs);
     HIPCHK(hipMemcpyAsync(tmp.data(), d_v, nproofs, hipMemcpyDeviceToHost, ctx->stream), "memcpy verdicts");

@@ -596,8 +596,8 @@ __global__ __launch_bounds__(64) void k_wipv_hash2(int k, int m, size_t nproofs,
 }
 
 __global__ __launch_bounds__(64) void k_wipv_consts(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
-                                                    const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF, fq* __restrict__ varS,
-                                                    fqm* __restrict__ cst, int* __restrict__ bad) {
+                                                    const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF, fqm* __restrict__ scF,
+                                                    fq* __restrict__ varS, fqm* __restrict__ cst, int* __restrict__ bad) {
     size_t pr = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (pr >= nproofs || bad[pr]) return;
     const int nm = n_bits * m;
@@ -680,9 +680,14 @@ __global__ __launch_bounds__(64) void k_wipv_consts(const uint8_t* __restrict__ 
     fqm zeta = fqm_sub(fqm_mul(fqm_sub(z_m, zsq), sum_y), fqm_mul(fqm_mul(z_m, ynm1), sum_d));
     // g : r' s' y - e^2 zeta ; h : delta'                                      :532-535, 598
     fqm sG = fqm_sub(fqm_mul(fqm_mul(r_m, s_m), y_m), fqm_mul(esq, zeta));
-    tdig_t* dg = digF + pr * (size_t)(2 * nm + 2) * W;
-    store_digits(fqm_to_fq(sG), c, W, dg + (size_t)(2 * nm) * W);
-    store_digits(fqm_to_fq(dl_m), c, W, dg + (size_t)(2 * nm + 1) * W);
+    if (scF) {  // random-linear-combination mode: the scalars themselves, Montgomery form
+        scF[pr * (size_t)(2 * nm + 2) + 2 * nm] = sG;
+        scF[pr * (size_t)(2 * nm + 2) + 2 * nm + 1] = dl_m;
+    } else {
+        tdig_t* dg = digF + pr * (size_t)(2 * nm + 2) * W;
+        store_digits(fqm_to_fq(sG), c, W, dg + (size_t)(2 * nm) * W);
+        store_digits(fqm_to_fq(dl_m), c, W, dg + (size_t)(2 * nm + 1) * W);
+    }
     vs[0] = fqm_to_fq(mesq);                    // A (range proof) : -e^2     :564-565
     vs[1 + 2 * k] = fqm_to_fq(fqm_neg(e_m));    // a_tag : -e                 :574
     cs[CS_Z] = fqm_mul(esq, z_m);               // e^2 z                      :539
@@ -692,8 +697,8 @@ __global__ __launch_bounds__(64) void k_wipv_consts(const uint8_t* __restrict__ 
 }
 
 hipError_t launch_wipv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
-                                       const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fq* varS, fq* chal, fq* cst,
-                                       xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st) {
+                                       const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fqm* scF, fq* varS, fq* chal,
+                                       fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st) {
     const int nm = n_bits * m;
     hipLaunchKernelGGL(k_wipv_hash1, dim3((unsigned)((nproofs * (k + 2) + 63) / 64)), dim3(64), 0, st, proofs, proof_len, k, m, nm, nproofs, pts,
                        gens, chal, bad);
@@ -702,9 +707,9 @@ hipError_t launch_wipv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, 
     hipLaunchKernelGGL(k_wipv_fixinv, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, nproofs, fixres, fixaff, bad);
     hipLaunchKernelGGL(k_wipv_hash2, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, k, m, nproofs, pts, fixaff, chal, bad);
     hipLaunchKernelGGL(k_wipv_consts, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W,
-                       digF, varS, reinterpret_cast<fqm*>(cst), bad);
+                       digF, scF, varS, reinterpret_cast<fqm*>(cst), bad);
     hipLaunchKernelGGL(k_bpv_vec, dim3((unsigned)((nproofs * (size_t)nm + 255) / 256)), dim3(256), 0, st, n_bits, m, k, nproofs,
-                       reinterpret_cast<const fqm*>(cst), c, W, digF, (fqm*)nullptr, bad, 1);
+                       reinterpret_cast<const fqm*>(cst), c, W, digF, scF, bad, 1);
     return hipGetLastError();
 }
 

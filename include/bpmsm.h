@@ -216,6 +216,15 @@ int bp_wip_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits,
 int bp_wip_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
                                           const void* d_coms_xy, size_t nproofs, void* d_verdicts);
 
+/* Random-linear-combination form of the Bulletproofs+ batch verifier: same verdict bytes through one combined check
+ * (weights from `seed`, 32 bytes of caller randomness drawn after the proofs are fixed), per-proof fallback when it
+ * fails — see bp_rangeproof_verify_batch_rlc. */
+int bp_wip_rangeproof_verify_batch_rlc(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
+                                       const uint8_t* coms_xy, size_t nproofs, const uint8_t seed[32], uint8_t* verdicts, int* used_fallback);
+int bp_wip_rangeproof_verify_batch_rlc_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
+                                              const void* d_coms_xy, size_t nproofs, const uint8_t seed[32], void* d_verdicts,
+                                              int* used_fallback);
+
 /* Bulletproofs+ : `RangeProofWIP::prove` (range_proof_wip.rs:101-274) with
  * `WeightedInnerProdArg::prove` (weighted_inner_product.rs:47-268); tape = alpha, then (d_L, d_R) per
  * round, then r, s, delta, eta (1 + 2 log2(nm) + 4 scalars).  Proof = 195 + 66 log2(nm) bytes.

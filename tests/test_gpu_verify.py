@@ -273,3 +273,55 @@ def test_bpplus_batch_rejects_bad_sizes(ctx):
         assert e.value.code == -1
     finally:
         gens.close()
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_bpplus_rlc_cases(ctx, idx):
+    """bp_wip_rangeproof_verify_batch_rlc: the valid golden proof repeated passes the combined check (no fallback);
+    with the tampered variants in the batch the per-proof kernel decides and the verdicts are the oracle's."""
+    from _golden import bpplus_cases
+    case = bpplus_cases()[idx]
+    n, m = case["n"], case["m"]
+    gens, _, _ = _plus_gens(ctx, n, m)
+    try:
+        proofs, coms, want = _case_batch(case)
+        seed = bytes(range(7, 39))
+        got, fb = ctx.wip_rangeproof_verify_batch_rlc(gens, n, m, proofs[0] * 6, coms[0] * 6, seed)
+        assert got == [0] * 6 and not fb
+        got, fb = ctx.wip_rangeproof_verify_batch_rlc(gens, n, m, b"".join(proofs) * 3, b"".join(coms) * 3, seed)
+        assert got == want * 3 and fb
+    finally:
+        gens.close()
+
+
+def test_bpplus_rlc_many_distinct_and_malformed(ctx, oracle_c):
+    """80 distinct valid n=64 m=1 Bulletproofs+ proofs pass the combined check with and without malformed proofs among
+    them (weight 0, verdict 255); one tampered proof sends the batch to the per-proof path with identical verdicts."""
+    from oracle import tape
+    n, m, k = 64, 1, 6
+    gens, G, H = _plus_gens(ctx, n, m, window_bits=10)
+    Gp, Hp = ec.dec64(G), ec.dec64(H)
+    try:
+        proofs, coms = [], []
+        for i in range(80):
+            tb = tape.make_tape_bytes("plusrlc%d" % i, m + 1 + 2 * k + 4)
+            v = (i * 0x9E3779B97F4A7C15) & ((1 << n) - 1)
+            r = int.from_bytes(tb[:32], "big")
+            coms.append(ec.enc64(oracle_c.add(oracle_c.mul(Gp, v), oracle_c.mul(Hp, r))))
+            proofs.append(ctx.wip_rangeproof_prove(gens, n, v.to_bytes(32, "big"), tb[:32], tb[32:]))
+        seed = b"\x5a" * 32
+        got, fb = ctx.wip_rangeproof_verify_batch_rlc(gens, n, m, b"".join(proofs), b"".join(coms), seed)
+        assert got == [0] * 80 and not fb
+        bad = list(proofs)
+        bad[11] = b"\x02" + b"\x00" * 31 + b"\x05" + bad[11][33:]  # A: x = 5 is not on the curve -> would not deserialize
+        bad[40] = bad[40][:33 * 15] + b"\xff" * 32 + bad[40][33 * 15 + 32:]  # r' >= q
+        got, fb = ctx.wip_rangeproof_verify_batch_rlc(gens, n, m, b"".join(bad), b"".join(coms), seed)
+        assert not fb and got == [255 if i in (11, 40) else 0 for i in range(80)]
+        t = bytearray(bad[63])
+        t[33 * 15 + 64 + 20] ^= 4  # delta'
+        bad[63] = bytes(t)
+        got, fb = ctx.wip_rangeproof_verify_batch_rlc(gens, n, m, b"".join(bad), b"".join(coms), seed)
+        assert fb and got == [255 if i in (11, 40) else (3 if i == 63 else 0) for i in range(80)]
+        assert got == ctx.wip_rangeproof_verify_batch(gens, n, m, b"".join(bad), b"".join(coms))
+    finally:
+        gens.close()
