@@ -51,3 +51,23 @@ def test_product_does_not_import_oracle():
             if fn.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, fn), errors="replace").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, fn
+
+
+def test_rust_sys_crate_declares_every_export():
+    """rust/bpmsm-sys/src/lib.rs (the FFI crate a Rust deployment binds; not compilable here: no cargo)
+    declares every function include/bpmsm.h does, with the same number of parameters."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "bpmsm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    rs = open(os.path.join(root, "rust", "bpmsm-sys", "src", "lib.rs")).read()
+    rs = re.sub(r"//.*", "", rs)
+    cdecl = {m.group(1): m.group(2) for m in re.finditer(r"\b(bp_[a-z0-9_]+)\s*\(([^;{]*)\)\s*;", hdr)}
+    rdecl = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (bp_[a-z0-9_]+)\s*\(([^;]*?)\)\s*(?:->\s*[^;]+)?;", rs, flags=re.S)}
+    assert cdecl, "no declarations parsed"
+    for name, args in cdecl.items():
+        assert name in rdecl, name
+        nc = 0 if args.strip() in ("", "void") else args.count(",") + 1
+        nr = 0 if not rdecl[name].strip() else rdecl[name].count(",") + 1
+        assert nc == nr, (name, nc, nr)
