@@ -284,6 +284,16 @@ def bench_prove(args):
             row["prove_per_s_%d_contexts" % nthr] = nthr * per / dtp
             for c in ctxs:
                 c.close()
+        # batch prover: N proofs per call, one GPU launch per protocol step for all of them, scalar work on host threads
+        nb = {1: 512, 16: 128, 64: 32}.get(m, 64)
+        pb = ctx.wip_rangeproof_prove_batch if kind else ctx.rangeproof_prove_batch
+        pb(gens, n, m, sec * 8, bl * 8, tape * 8, len(tape))
+        t0 = time.perf_counter()
+        got = pb(gens, n, m, sec * nb, bl * nb, tape * nb, len(tape))
+        dtb = time.perf_counter() - t0
+        assert got[0] == proof and got[-1] == proof and len(got) == nb
+        row["prove_batch_per_s"] = nb / dtb
+        row["prove_batch_size"] = nb
         rows.append(row)
         gens.close()
     out = {"metric": "single-proof latency (ms), secp256k1 range proofs through the C ABI", "unit": "ms", "n_gpus": 1,

@@ -45,6 +45,8 @@ EXPORTED_SYMBOLS = [
     "bp_generate_bases",
     "bp_generate_bases_device",
     "bp_rangeproof_prove",
+    "bp_rangeproof_prove_batch",
+    "bp_wip_rangeproof_prove_batch",
     "bp_rangeproof_verify",
     "bp_wip_rangeproof_prove",
     "bp_wip_rangeproof_verify",
@@ -143,6 +145,9 @@ def lib():
     L.bp_msm_batch.restype = i32
     L.bp_generate_bases.argtypes = [i32, ctypes.c_uint64, sz, sz, cp, cp, cp, cp]
     L.bp_generate_bases.restype = i32
+    for f in (L.bp_rangeproof_prove_batch, L.bp_wip_rangeproof_prove_batch):
+        f.argtypes = [vp, vp, i32, i32, sz, cp, cp, cp, sz, cp, sz, ctypes.POINTER(i32)]
+        f.restype = i32
     L.bp_generate_bases_device.argtypes = [vp, i32, ctypes.c_uint64, sz, sz, cp, cp, cp, cp]
     L.bp_generate_bases_device.restype = i32
     prove_args = [vp, vp, i32, cp, cp, i32, cp, sz, cp, sz, ctypes.POINTER(sz)]
@@ -400,6 +405,25 @@ class Context:
     def wip_rangeproof_prove(self, gens, n_bits, secrets_be, blindings_be, tape):
         """`RangeProofWIP::prove`; tape = alpha, (d_L, d_R) per round, r, s, delta, eta."""
         return self._prove(lib().bp_wip_rangeproof_prove, gens, n_bits, secrets_be, blindings_be, tape)
+
+    def _prove_batch(self, fn, plen0, gens, n_bits, m, secrets_be, blindings_be, tapes, tape_len):
+        nproofs = len(secrets_be) // (32 * m)
+        nm = n_bits * m
+        proof_len = plen0 + 66 * max(nm.bit_length() - 1, 0)
+        if len(secrets_be) != nproofs * m * 32 or len(blindings_be) != nproofs * m * 32 or len(tapes) != nproofs * tape_len:
+            raise BpError(BP_EINVAL, "secrets/blindings/tapes length mismatch")
+        out = ctypes.create_string_buffer(max(nproofs * proof_len, 1))
+        st = (ctypes.c_int32 * max(nproofs, 1))()
+        _check(fn(self._h, gens._h, n_bits, m, nproofs, bytes(secrets_be), bytes(blindings_be), bytes(tapes), tape_len, out, proof_len, st))
+        return [out.raw[i * proof_len:(i + 1) * proof_len] for i in range(nproofs)]
+
+    def rangeproof_prove_batch(self, gens, n_bits, m, secrets_be, blindings_be, tapes, tape_len):
+        """`RangeProof::prove` for len(secrets_be)//(32 m) proofs (one GPU launch per protocol step for all) -> list of proofs."""
+        return self._prove_batch(lib().bp_rangeproof_prove_batch, 292, gens, n_bits, m, secrets_be, blindings_be, tapes, tape_len)
+
+    def wip_rangeproof_prove_batch(self, gens, n_bits, m, secrets_be, blindings_be, tapes, tape_len):
+        """`RangeProofWIP::prove` for a batch -> list of proofs."""
+        return self._prove_batch(lib().bp_wip_rangeproof_prove_batch, 195, gens, n_bits, m, secrets_be, blindings_be, tapes, tape_len)
 
     def rangeproof_verify(self, gens, n_bits, m, proof, coms_xy, mode=2):
         """mode 0 = verify, 1 = fast_verify, 2 = aggregated_verify -> verdict code."""

@@ -81,7 +81,7 @@ size_t bpv_msm_vartab_bytes(int tp, size_t nproofs);
 
 
 // msm_batch.hip
-hipError_t launch_mb_digits(const uint8_t* scalars_be, size_t total, int c, int W, tdig_t* digits, hipStream_t st);
+hipError_t launch_mb_digits(const uint8_t* scalars_be, size_t total, int c, int W, tdig_t* digits, hipStream_t st, int mont = 0);
 size_t mb_vartab_bytes(size_t njobs);
 hipError_t launch_mb_msm(size_t njobs, int np, const affine_mem* table, int c, int W, const tdig_t* digF, const uint8_t* has_gen,
                          const affine_mem* xpts, const uint8_t* xsc_be, const uint32_t* xoff, xyzz* vartab, xyzz* out, hipStream_t st);

@@ -17,10 +17,21 @@
 
 namespace bp {
 
-__global__ void k_mb_digits(const uint8_t* __restrict__ scalars_be, size_t total, int c, int W, tdig_t* __restrict__ digits) {
+// mont != 0: the 32 bytes are the host scalar class's Montgomery limbs (hostmath.h Fq: little-endian words of x R mod q,
+// R = 2^256) and the conversion to the plain value happens here, one lane per scalar, instead of one Montgomery product
+// per term on a host thread (the protocol layer uploads thousands of terms per call).
+__global__ void k_mb_digits(const uint8_t* __restrict__ scalars_be, size_t total, int c, int W, tdig_t* __restrict__ digits, int mont) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    fq k = fq_from_be_reduce(scalars_be + 32 * i);
+    fq k;
+    if (mont) {
+        const uint32_t* wsrc = reinterpret_cast<const uint32_t*>(scalars_be + 32 * i);
+#pragma unroll
+        for (int j = 0; j < 8; j++) k.v[j] = wsrc[j];
+        k = fq_from_mont(k);
+    } else {
+        k = fq_from_be_reduce(scalars_be + 32 * i);
+    }
     tdig_t* out = digits + i * (size_t)W;
     uint32_t carry = 0;
     const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
@@ -93,9 +104,9 @@ __global__ __launch_bounds__(256, 2) void k_mb_msm(size_t njobs, int np, const a
     if (lane == 0 && job < njobs) out[job] = red[tid];
 }
 
-hipError_t launch_mb_digits(const uint8_t* scalars_be, size_t total, int c, int W, tdig_t* digits, hipStream_t st) {
+hipError_t launch_mb_digits(const uint8_t* scalars_be, size_t total, int c, int W, tdig_t* digits, hipStream_t st, int mont) {
     if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_mb_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scalars_be, total, c, W, digits);
+    hipLaunchKernelGGL(k_mb_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scalars_be, total, c, W, digits, mont);
     return hipGetLastError();
 }
 size_t mb_vartab_bytes(size_t njobs) {

@@ -14,7 +14,9 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -171,11 +173,19 @@ int pin_reserve(bp_ctx* ctx, size_t bytes) {
     return BP_OK;
 }
 
-int fbmsm(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs, Pt* out) {
+int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_in, Pt* out, const std::vector<const FbJob*>* jobs_ptr = nullptr) {
+    // jobs either by value (one caller) or as pointers into several callers' vectors (FbBatcher)
+    struct View {
+        const std::vector<FbJob>* v;
+        const std::vector<const FbJob*>* p;
+        size_t size() const { return p ? p->size() : v->size(); }
+        const FbJob& operator[](size_t i) const { return p ? *(*p)[i] : (*v)[i]; }
+    } jobs{&jobs_in, jobs_ptr};
     const size_t nj = jobs.size();
     if (!nj) return BP_OK;
     size_t nt = 0, nx = 0, max_t = 0, max_x = 0;
-    for (auto& j : jobs) {
+    for (size_t jj = 0; jj < nj; jj++) {
+        const FbJob& j = jobs[jj];
         nt += j.gi.size();
         nx += j.xp.size();
         if (j.gi.size() > max_t) max_t = j.gi.size();
@@ -216,7 +226,7 @@ int fbmsm(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs, Pt* out
                 return BP_EINVAL;
             }
             h_gidx[t] = jobs[j].gi[i];
-            jobs[j].gs[i].to_be(hp + o_sc + 32 * t);
+            memcpy(hp + o_sc + 32 * t, jobs[j].gs[i].m, 32);  // Montgomery limbs; k_mb_digits converts (mont = 1)
         }
         for (size_t i = 0; i < jobs[j].xp.size(); i++, x++) {
             memcpy(hp + o_xbe + 64 * x, jobs[j].xp[i].b, 64);
@@ -234,7 +244,7 @@ int fbmsm(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs, Pt* out
     HIPCHK(hipMemsetAsync(d_err, 0, sizeof(int), st), "memset");
     HIPCHK(hipMemcpyAsync(d, hp, up_bytes, hipMemcpyHostToDevice, st), "h2d");
     if (nx) HIPCHK(launch_ingest_points(d + o_xbe, d_xpts, nx, d_err, st), "ingest");
-    if (nt) HIPCHK(launch_mb_digits(d + o_sc, nt, g->c, W, (tdig_t*)ctx->fb[1].p, st), "digits");
+    if (nt) HIPCHK(launch_mb_digits(d + o_sc, nt, g->c, W, (tdig_t*)ctx->fb[1].p, st, 1), "digits");
     HIPCHK(launch_fb_msm(nj, g->d_table, W, NB, (const tdig_t*)ctx->fb[1].p, (const uint32_t*)(d + o_gidx), (const uint32_t*)(d + o_toff), d_xpts,
                          d + o_xsc, (const uint32_t*)(d + o_xoff), nblk, nxblk, (xyzz*)ctx->vartab.p, d_partial, d_out, st),
            "fb_msm");
@@ -249,6 +259,66 @@ int fbmsm(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs, Pt* out
     }
     for (size_t j = 0; j < nj; j++) memcpy(out[j].b, h_out + 64 * j, 64);
     return BP_OK;
+}
+
+// Batch provers (bp_rangeproof_prove_batch): N proofs run the unchanged single-proof code on N host threads; their
+// table-MSM calls meet here and go to the GPU as ONE launch per protocol step (all proofs of a batch take the same
+// steps: same n, m), so a batch costs as many launches and synchronisations as one proof while the per-proof scalar
+// work (host, as in the reference) runs on all cores.  The last thread to arrive performs the launch for everyone.
+struct FbBatcher {
+    bp_ctx* ctx;
+    const bp_gens* g;
+    std::mutex mu;
+    std::condition_variable cv;
+    int active = 0, waiting = 0;
+    uint64_t gen = 0;
+    int rc = BP_OK;
+    std::vector<const std::vector<FbJob>*> pj;
+    std::vector<Pt*> po;
+
+    void flush_locked() {  // mu held; every active thread is waiting
+        std::vector<const FbJob*> all;
+        for (auto* v : pj)
+            for (auto& j : *v) all.push_back(&j);
+        const size_t total = all.size();
+        std::vector<Pt> res(total);
+        static const std::vector<FbJob> none;
+        rc = total ? fbmsm_direct(ctx, g, none, res.data(), &all) : BP_OK;
+        if (rc == BP_OK) {
+            size_t o = 0;
+            for (size_t i = 0; i < pj.size(); i++)
+                for (size_t j = 0; j < pj[i]->size(); j++) po[i][j] = res[o++];
+        }
+        pj.clear();
+        po.clear();
+        waiting = 0;
+        gen++;
+        cv.notify_all();
+    }
+    int submit(const std::vector<FbJob>& jobs, Pt* out) {
+        std::unique_lock<std::mutex> lk(mu);
+        pj.push_back(&jobs);
+        po.push_back(out);
+        waiting++;
+        if (waiting == active) {
+            flush_locked();
+            return rc;
+        }
+        const uint64_t my = gen;
+        cv.wait(lk, [&] { return gen != my; });
+        return rc;
+    }
+    void leave() {  // a proof finished (or failed): the others must not wait for it
+        std::unique_lock<std::mutex> lk(mu);
+        active--;
+        if (waiting > 0 && waiting == active) flush_locked();
+    }
+};
+thread_local FbBatcher* tl_batcher = nullptr;
+
+int fbmsm(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs, Pt* out) {
+    if (tl_batcher) return tl_batcher->submit(jobs, out);
+    return fbmsm_direct(ctx, g, jobs, out);
 }
 
 // ---- shared pieces -------------------------------------------------------------------------------
@@ -711,7 +781,9 @@ int bp_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint
     }
     const size_t plen = 292 + 66 * (size_t)k;
     if (proof_cap < plen || tape_len < 32 * (2 * nm + 4)) return BP_EINVAL;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::unique_lock<std::mutex> lk(ctx->mu, std::defer_lock);
+    if (!tl_batcher) lk.lock();  // inside a batch the batch call holds ctx->mu and only the batcher touches the context
+    else if (ctx->proto_path != 0) return BP_EINVAL;
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     Gens gn(gens);
     Tape tp{tape, tape_len};
@@ -1206,7 +1278,9 @@ int bp_wip_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const 
     }
     const size_t plen = 195 + 66 * (size_t)k;
     if (proof_cap < plen || tape_len < 32 * (size_t)(1 + 2 * k + 4)) return BP_EINVAL;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::unique_lock<std::mutex> lk(ctx->mu, std::defer_lock);
+    if (!tl_batcher) lk.lock();
+    else if (ctx->proto_path != 0) return BP_EINVAL;
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     Gens gn(gens);
     Tape tp{tape, tape_len};
@@ -1356,6 +1430,74 @@ int bp_wip_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
     RC(fbmsm(ctx, gens, jobs, &rhs));
     *verdict = (r1[1] == rhs) ? BP_VERDICT_OK : BP_VERDICT_RANGE_PROOF_ERROR;
     return BP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Batch provers: N independent proofs over the same generators.  Every proof runs the single-proof code above on its
+// own host thread; their table-MSM calls are merged into one GPU launch per protocol step (FbBatcher).
+static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, size_t nproofs, const uint8_t* secrets_be,
+                            const uint8_t* blindings_be, const uint8_t* tapes, size_t tape_len, uint8_t* proofs_out, size_t proof_len, int* status,
+                            int wip) {
+    if (!ctx || !gens || n_bits <= 0 || m <= 0) return BP_EINVAL;
+    if (nproofs == 0) return BP_OK;
+    if (!secrets_be || !blindings_be || !tapes || !proofs_out) return BP_EINVAL;
+    const size_t nm = (size_t)n_bits * (size_t)m;
+    const int k = log2_exact(nm);
+    if (k < 0 || nm != gens->nm || gens->device != ctx->device || proof_len != (size_t)(wip ? 195 : 292) + 66 * (size_t)k) {
+        set_error_msg("prove_batch: n_bits*m must be a power of two equal to the generators' nm; proof_len = 292 (195 for BP+) + 66 log2(nm)");
+        return BP_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->proto_path != 0) {
+        set_error_msg("prove_batch needs the fixed-base table path (bp_proto_set_path(ctx, 0))");
+        return BP_EINVAL;
+    }
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t kChunk = 128;  // proofs (host threads) in flight
+    int first_err = BP_OK;
+    std::vector<int> st(nproofs, BP_OK);
+    for (size_t base = 0; base < nproofs; base += kChunk) {
+        const size_t cnt = nproofs - base < kChunk ? nproofs - base : kChunk;
+        FbBatcher b;
+        b.ctx = ctx;
+        b.g = gens;
+        b.active = (int)cnt;
+        std::vector<std::thread> thr;
+        thr.reserve(cnt);
+        for (size_t t = 0; t < cnt; t++) {
+            const size_t i = base + t;
+            thr.emplace_back([&, i] {
+                tl_batcher = &b;
+                size_t len = 0;
+                const uint8_t* sec = secrets_be + i * (size_t)m * 32;
+                const uint8_t* bl = blindings_be + i * (size_t)m * 32;
+                const uint8_t* tp = tapes + i * tape_len;
+                uint8_t* out = proofs_out + i * proof_len;
+                st[i] = wip ? bp_wip_rangeproof_prove(ctx, gens, n_bits, sec, bl, m, tp, tape_len, out, proof_len, &len)
+                            : bp_rangeproof_prove(ctx, gens, n_bits, sec, bl, m, tp, tape_len, out, proof_len, &len);
+                tl_batcher = nullptr;
+                b.leave();
+            });
+        }
+        for (auto& t : thr) t.join();
+    }
+    for (size_t i = 0; i < nproofs; i++) {
+        if (status) status[i] = st[i];
+        if (st[i] != BP_OK && first_err == BP_OK) first_err = st[i];
+    }
+    if (first_err != BP_OK) set_error_msg("prove_batch: at least one proof failed (see the per-proof status codes)");
+    return first_err;
+}
+
+int bp_rangeproof_prove_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, size_t nproofs, const uint8_t* secrets_be,
+                              const uint8_t* blindings_be, const uint8_t* tapes, size_t tape_len, uint8_t* proofs_out, size_t proof_len,
+                              int* status) {
+    return prove_batch_impl(ctx, gens, n_bits, m, nproofs, secrets_be, blindings_be, tapes, tape_len, proofs_out, proof_len, status, 0);
+}
+int bp_wip_rangeproof_prove_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, size_t nproofs, const uint8_t* secrets_be,
+                                  const uint8_t* blindings_be, const uint8_t* tapes, size_t tape_len, uint8_t* proofs_out, size_t proof_len,
+                                  int* status) {
+    return prove_batch_impl(ctx, gens, n_bits, m, nproofs, secrets_be, blindings_be, tapes, tape_len, proofs_out, proof_len, status, 1);
 }
 
 }  // extern "C"

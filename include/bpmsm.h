@@ -195,6 +195,20 @@ int bp_generate_bases_device(bp_ctx* ctx, int kind, uint64_t seed, size_t n_bits
 int bp_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint8_t* secrets_be, const uint8_t* blindings_be, int m,
                         const uint8_t* tape, size_t tape_len, uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
 
+/* bp_rangeproof_prove_batch / bp_wip_rangeproof_prove_batch — `RangeProof::prove` (range_proof.rs:45-263) /
+ * `RangeProofWIP::prove` (range_proof_wip.rs:101-274) for nproofs independent proofs over the same generators, each
+ * byte-identical to the single-proof call on the same inputs.  Proof i uses secrets_be / blindings_be [i*m .. i*m+m)
+ * (32 B each) and tapes[i*tape_len ..] (the single-proof tape layout); proofs_out receives nproofs * proof_len bytes
+ * (proof_len = 292 + 66 k, 195 + 66 k for Bulletproofs+).  The per-proof scalar work runs on host threads (up to 128
+ * proofs in flight) and every protocol step of all of them is ONE GPU launch.  status (nullable) receives the per-proof
+ * return codes; the call returns the first failing one.  Needs the fixed-base table path (bp_proto_set_path 0). */
+int bp_rangeproof_prove_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, size_t nproofs, const uint8_t* secrets_be,
+                              const uint8_t* blindings_be, const uint8_t* tapes, size_t tape_len, uint8_t* proofs_out, size_t proof_len,
+                              int* status);
+int bp_wip_rangeproof_prove_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, size_t nproofs, const uint8_t* secrets_be,
+                                  const uint8_t* blindings_be, const uint8_t* tapes, size_t tape_len, uint8_t* proofs_out, size_t proof_len,
+                                  int* status);
+
 /* bp_rangeproof_verify — one proof through `RangeProof::verify` (mode 0, range_proof.rs:265-398, with
  * the recursive `InnerProductArg::verify`), `fast_verify` (mode 1, :400-535 + inner_product.rs:253-345)
  * or `aggregated_verify` (mode 2, :537-782).  *verdict receives a BP_VERDICT_* code. */

@@ -87,6 +87,12 @@ extern "C" {
     pub fn bp_rangeproof_prove(ctx: *mut bp_ctx, gens: *const bp_gens, n_bits: c_int, secrets_be: *const u8, blindings_be: *const u8,
                                m: c_int, tape: *const u8, tape_len: usize, proof_out: *mut u8, proof_cap: usize,
                                proof_len: *mut usize) -> c_int;
+    pub fn bp_rangeproof_prove_batch(ctx: *mut bp_ctx, gens: *const bp_gens, n_bits: c_int, m: c_int, nproofs: usize, secrets_be: *const u8,
+                                     blindings_be: *const u8, tapes: *const u8, tape_len: usize, proofs_out: *mut u8, proof_len: usize,
+                                     status: *mut c_int) -> c_int;
+    pub fn bp_wip_rangeproof_prove_batch(ctx: *mut bp_ctx, gens: *const bp_gens, n_bits: c_int, m: c_int, nproofs: usize,
+                                         secrets_be: *const u8, blindings_be: *const u8, tapes: *const u8, tape_len: usize,
+                                         proofs_out: *mut u8, proof_len: usize, status: *mut c_int) -> c_int;
     pub fn bp_rangeproof_verify(ctx: *mut bp_ctx, gens: *const bp_gens, n_bits: c_int, m: c_int, proof: *const u8, proof_len: usize,
                                 coms_xy: *const u8, mode: c_int, verdict: *mut u8) -> c_int;
     pub fn bp_rangeproof_verify_batch(ctx: *mut bp_ctx, gens: *const bp_gens, n_bits: c_int, m: c_int, proofs: *const u8,

@@ -197,3 +197,54 @@ def test_generate_bases_on_device_matches_host_and_oracle(ctx, kind, seed, n, m)
         assert got[0][:64 * min(nm, 8)] == b"".join(lab(seed + i) for i in range(min(nm, 8)))
         assert got[1][:64 * min(nm, 8)] == b"".join(lab(seed + n + i) for i in range(min(nm, 8)))
         assert got[3] == lab(1 if kind == 0 else seed - 1)
+
+
+@pytest.mark.parametrize("kind,n,m,count", [(0, 64, 1, 40), (0, 16, 2, 7), (1, 64, 1, 33), (1, 8, 4, 5), (0, 64, 1, 150)])
+def test_prove_batch_matches_single_proofs(ctx, kind, n, m, count):
+    """bp_rangeproof_prove_batch / bp_wip_rangeproof_prove_batch (one GPU launch per protocol step for all proofs, the
+    scalar work of every proof on its own host thread): every proof byte-identical to the single-proof call on the same
+    inputs (whose bytes the tests above pin to the oracle), more proofs than one 128-thread chunk, and all of them verify."""
+    from oracle import tape
+    g, h, G, H = bpa.generate_bases(kind, bpa.KZEN_SEED, n, m)
+    gens = bpa.Gens(ctx, g, h, G, H, 8)
+    try:
+        nm = n * m
+        k = nm.bit_length() - 1
+        ntape = (1 + 2 * k + 4) if kind else (2 + 2 * nm + 2)
+        rng = random.Random(1000 * kind + n + m)
+        secs, blinds, tapes = b"", b"", b""
+        for i in range(count):
+            tb = tape.make_tape_bytes("pb-%d-%d-%d-%d" % (kind, n, m, i), m + ntape)
+            secs += b"".join(rng.randrange(1 << n).to_bytes(32, "big") for _ in range(m))
+            blinds += tb[:32 * m]
+            tapes += tb[32 * m:]
+        batch = (ctx.wip_rangeproof_prove_batch if kind else ctx.rangeproof_prove_batch)(gens, n, m, secs, blinds, tapes, 32 * ntape)
+        single = ctx.wip_rangeproof_prove if kind else ctx.rangeproof_prove
+        assert len(batch) == count
+        step = 1 if count <= 40 else 9
+        for i in range(0, count, step):
+            want = single(gens, n, secs[32 * m * i:32 * m * (i + 1)], blinds[32 * m * i:32 * m * (i + 1)], tapes[32 * ntape * i:32 * ntape * (i + 1)])
+            assert batch[i] == want, i
+        # all of them verify against commitments made on the GPU (V_j = v_j G + r_j H)
+        coms = b"".join(ctx.msm(G + H, secs[32 * j:32 * j + 32] + blinds[32 * j:32 * j + 32], None) for j in range(count * m))
+        verify = ctx.wip_rangeproof_verify_batch if kind else ctx.rangeproof_verify_batch
+        assert verify(gens, n, m, b"".join(batch), coms) == [0] * count
+    finally:
+        gens.close()
+
+
+def test_prove_batch_reports_bad_inputs(ctx):
+    g, h, G, H = bpa.generate_bases(0, bpa.KZEN_SEED, 8, 1)
+    gens = bpa.Gens(ctx, g, h, G, H, 4)
+    try:
+        with pytest.raises(bpa.BpError) as e:  # zero scalars on the tape: the reference's Scalar::random() never yields them
+            ctx.rangeproof_prove_batch(gens, 8, 1, (5).to_bytes(32, "big") * 3, (7).to_bytes(32, "big") * 3, b"\0" * (32 * 20 * 3), 32 * 20)
+        assert e.value.code == -1
+        ctx.set_proto_path(1)
+        try:
+            with pytest.raises(bpa.BpError):
+                ctx.rangeproof_prove_batch(gens, 8, 1, (5).to_bytes(32, "big"), (7).to_bytes(32, "big"), b"\x01" * (32 * 20), 32 * 20)
+        finally:
+            ctx.set_proto_path(0)
+    finally:
+        gens.close()
