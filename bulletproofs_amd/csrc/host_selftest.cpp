@@ -122,6 +122,8 @@ int bpt_ec_decompress(uint8_t* out, const uint8_t* in33) {
     affine_to_be64(out, p);
     return 0;
 }
+int bpt_host_decompress(uint8_t* out, const uint8_t* in33) { return host_decompress(in33, out) ? 1 : 0; }
+void bpt_fp64_mul(uint8_t* out, const uint8_t* a, const uint8_t* b) { (Fp64::from_be(a) * Fp64::from_be(b)).to_be(out); }
 int bpt_ec_on_curve(const uint8_t* a) { return affine_on_curve(affine_from_be64(a)) ? 1 : 0; }
 
 void bpt_sha256(uint8_t* out, const uint8_t* data, uint32_t len) {

@@ -273,8 +273,174 @@ struct Transcript {
     }
 };
 
+// ---- base field on 4x64-bit limbs (host only): decompression of proof points ------------------------
+// The single-proof verifiers parse 4 + 2k compressed points per proof on the host (curv `Point::from_bytes`); with
+// the portable 9x29 code of fp.h (written for the GPU's 32-bit multiplier) one square root costs ~25 us of a host
+// core, a third of a verify call.  p = 2^256 - C, C = 2^32 + 977: schoolbook product, two folds, one subtraction.
+struct Fp64 {
+    uint64_t v[4];
+    static void mul(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+        typedef unsigned __int128 u128;
+        uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 4; i++) {
+            u128 c = 0;
+            for (int j = 0; j < 4; j++) {
+                c += (u128)a[i] * b[j] + t[i + j];
+                t[i + j] = (uint64_t)c;
+                c >>= 64;
+            }
+            t[i + 4] = (uint64_t)c;
+        }
+        const uint64_t C = 0x1000003D1ULL;
+        // fold 1: lo + hi * C  (5 limbs)
+        uint64_t f[5];
+        u128 c = 0;
+        for (int i = 0; i < 4; i++) {
+            c += (u128)t[4 + i] * C + t[i];
+            f[i] = (uint64_t)c;
+            c >>= 64;
+        }
+        f[4] = (uint64_t)c;
+        // fold 2: f[4] * C into the low limbs (f[4] < 2^34)
+        c = (u128)f[4] * C;
+        for (int i = 0; i < 4; i++) {
+            c += f[i];
+            f[i] = (uint64_t)c;
+            c >>= 64;
+        }
+        if ((uint64_t)c) {  // wrapped past 2^256 once more: add C (cannot carry again: the low limbs are tiny then)
+            u128 d = (u128)f[0] + C;
+            f[0] = (uint64_t)d;
+            d >>= 64;
+            for (int i = 1; i < 4 && (uint64_t)d; i++) {
+                d += f[i];
+                f[i] = (uint64_t)d;
+                d >>= 64;
+            }
+        }
+        // final: subtract p if >= p
+        const uint64_t P[4] = {0xFFFFFFFEFFFFFC2FULL, ~0ULL, ~0ULL, ~0ULL};
+        bool ge = true;
+        for (int i = 3; i >= 0; i--) {
+            if (f[i] != P[i]) {
+                ge = f[i] > P[i];
+                break;
+            }
+        }
+        if (ge) {
+            u128 bw = 0;
+            for (int i = 0; i < 4; i++) {
+                u128 d = (u128)f[i] - P[i] - (uint64_t)bw;
+                f[i] = (uint64_t)d;
+                bw = (d >> 64) & 1;
+            }
+        }
+        for (int i = 0; i < 4; i++) r[i] = f[i];
+    }
+    Fp64 operator*(const Fp64& o) const {
+        Fp64 r;
+        mul(r.v, v, o.v);
+        return r;
+    }
+    Fp64 sqr_n(int n) const {
+        Fp64 r = *this;
+        for (int i = 0; i < n; i++) r = r * r;
+        return r;
+    }
+    bool operator==(const Fp64& o) const { return v[0] == o.v[0] && v[1] == o.v[1] && v[2] == o.v[2] && v[3] == o.v[3]; }
+    static Fp64 from_be(const uint8_t* b) {
+        Fp64 r;
+        for (int i = 0; i < 4; i++) {
+            uint64_t w = 0;
+            for (int j = 0; j < 8; j++) w = (w << 8) | b[8 * (3 - i) + j];
+            r.v[i] = w;
+        }
+        return r;
+    }
+    void to_be(uint8_t* b) const {
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 8; j++) b[8 * (3 - i) + j] = (uint8_t)(v[i] >> (56 - 8 * j));
+    }
+    bool lt_p() const {
+        const uint64_t P[4] = {0xFFFFFFFEFFFFFC2FULL, ~0ULL, ~0ULL, ~0ULL};
+        for (int i = 3; i >= 0; i--)
+            if (v[i] != P[i]) return v[i] < P[i];
+        return false;
+    }
+    // a^((p+1)/4): the addition chain of fp_sqrt_candidate (fp.h)
+    Fp64 sqrt_candidate() const {
+        const Fp64& a = *this;
+        Fp64 x2 = a.sqr_n(1) * a;
+        Fp64 x3 = x2.sqr_n(1) * a;
+        Fp64 x6 = x3.sqr_n(3) * x3;
+        Fp64 x9 = x6.sqr_n(3) * x3;
+        Fp64 x11 = x9.sqr_n(2) * x2;
+        Fp64 x22 = x11.sqr_n(11) * x11;
+        Fp64 x44 = x22.sqr_n(22) * x22;
+        Fp64 x88 = x44.sqr_n(44) * x44;
+        Fp64 x176 = x88.sqr_n(88) * x88;
+        Fp64 x220 = x176.sqr_n(44) * x44;
+        Fp64 x223 = x220.sqr_n(3) * x3;
+        Fp64 t = x223.sqr_n(23) * x22;
+        t = t.sqr_n(6) * x2;
+        return t.sqr_n(2);
+    }
+};
+
 // ---- host point helpers (validation / compression only; no group law on the host) -----------------
+// 33-byte SEC1 compressed -> x || y (curv `Point::from_bytes`); same accept/reject rule as affine_decompress (ec.h)
 inline bool host_decompress(const uint8_t* b33, uint8_t out_xy[64]) {
+    if (b33[0] != 2 && b33[0] != 3) return false;
+    Fp64 x = Fp64::from_be(b33 + 1);
+    if (!x.lt_p()) return false;
+    Fp64 rhs = x * x * x;
+    {  // + 7
+        typedef unsigned __int128 u128;
+        u128 c = (u128)rhs.v[0] + 7;
+        rhs.v[0] = (uint64_t)c;
+        c >>= 64;
+        for (int i = 1; i < 4; i++) {
+            c += rhs.v[i];
+            rhs.v[i] = (uint64_t)c;
+            c >>= 64;
+        }
+        // a carry out of 2^256 or a value in [p, 2^256) can only follow rhs >= p - 7: renormalise through a product by one
+        if ((uint64_t)c || !rhs.lt_p()) {
+            // rhs (+ 2^256 if carry) mod p: add C for the carry, then reduce
+            if ((uint64_t)c) {
+                u128 d = (u128)rhs.v[0] + 0x1000003D1ULL;
+                rhs.v[0] = (uint64_t)d;
+                d >>= 64;
+                for (int i = 1; i < 4; i++) {
+                    d += rhs.v[i];
+                    rhs.v[i] = (uint64_t)d;
+                    d >>= 64;
+                }
+            }
+            Fp64 one;
+            one.v[0] = 1;
+            one.v[1] = one.v[2] = one.v[3] = 0;
+            rhs = rhs * one;
+        }
+    }
+    Fp64 y = rhs.sqrt_candidate();
+    if (!(y * y == rhs)) return false;
+    if ((y.v[0] & 1) != (uint64_t)(b33[0] & 1)) {  // y = p - y  (y != 0: the group has prime order)
+        typedef unsigned __int128 u128;
+        const uint64_t P[4] = {0xFFFFFFFEFFFFFC2FULL, ~0ULL, ~0ULL, ~0ULL};
+        u128 bw = 0;
+        for (int i = 0; i < 4; i++) {
+            u128 d = (u128)P[i] - y.v[i] - (uint64_t)bw;
+            y.v[i] = (uint64_t)d;
+            bw = (d >> 64) & 1;
+        }
+    }
+    x.to_be(out_xy);
+    y.to_be(out_xy + 32);
+    return true;
+}
+// the portable-field version (fp.h code path shared with the GPU), kept for the host self-test
+inline bool host_decompress_portable(const uint8_t* b33, uint8_t out_xy[64]) {
     affine a;
     if (!affine_decompress(a, b33)) return false;
     affine_to_be64(out_xy, a);

@@ -12,6 +12,7 @@
 // point P of RangeProof::prove (:221-244, only passed through InnerProductArg::prove, which never
 // reads it) and A_hat of RangeProofWIP::prove (:249-251, likewise); proof bytes are unaffected.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <condition_variable>
@@ -1453,7 +1454,8 @@ static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
         return BP_EINVAL;
     }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    const size_t kChunk = 128;  // proofs (host threads) in flight
+    size_t kChunk = 128;  // proofs (host threads) in flight
+    if (const char* e = getenv("BP_PROVE_CHUNK")) kChunk = (size_t)atol(e) >= 1 && (size_t)atol(e) <= 1024 ? (size_t)atol(e) : kChunk;
     int first_err = BP_OK;
     std::vector<int> st(nproofs, BP_OK);
     for (size_t base = 0; base < nproofs; base += kChunk) {

@@ -1,0 +1,10 @@
+"""Kernel timeline of the last N kernels from a rocprofv3 kernel-trace CSV (start/end relative, gaps)."""
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+n = int(sys.argv[2])
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))[-n:]
+t0 = int(rows[0]["Start_Timestamp"]); prev = t0
+for r in rows:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    print("%9.1f +%7.1f gap %7.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev) / 1e3, r["Kernel_Name"].split("(")[0].replace("bp::", "")))
+    prev = e

@@ -70,6 +70,33 @@ def test_fp_inv_var(L):
         assert call1(L.bpt_fp_inv_var, a) == call1(L.bpt_fp_inv, a)
 
 
+def test_host_fp64_and_decompress(L):
+    """The host-only 4x64-limb base field (hostmath.h Fp64: proof-point decompression of the single-proof verifiers)
+    against Python ints, and host_decompress against the portable decompression and the oracle on residues,
+    non-residues, both parities, x >= p and bad prefixes."""
+    rng = random.Random(71)
+    edge = [0, 1, 2, P - 1, P - 2, 2**32 + 977, 2**32 + 976, 2**255, (1 << 256) - 1 - 2**32 - 977 - 1, 2**64 - 1, 2**128 - 1, 2**192 - 1, P - 977]
+    vals = edge + [rng.randrange(P) for _ in range(300)]
+    for a in vals:
+        for b in rng.sample(vals, 6) + edge:
+            assert call2(L.bpt_fp64_mul, a, b) == a * b % P, (hex(a), hex(b))
+    xs = [0, 1, 2, 3, 5, P - 1, P - 2, P, P + 1, (1 << 256) - 1, ec.G[0]] + [rng.randrange(P) for _ in range(400)]
+    # x with x^3 + 7 close to p (the renormalisation branch)
+    xs += [x for x in range(1, 200)]
+    for x in xs:
+        for pre in (2, 3, 4, 0):
+            enc = bytes([pre]) + (x % (1 << 256)).to_bytes(32, "big")
+            o1 = ctypes.create_string_buffer(64)
+            o2 = ctypes.create_string_buffer(64)
+            r1 = L.bpt_host_decompress(o1, enc)
+            r2 = L.bpt_ec_decompress(o2, enc)
+            assert bool(r1) == (r2 == 0), (pre, hex(x))
+            if r1:
+                assert o1.raw == o2.raw, (pre, hex(x))
+                y = int.from_bytes(o1.raw[32:], "big")
+                assert (y * y - x * x * x - 7) % P == 0 and (y & 1) == (pre & 1)
+
+
 def test_fq(L):
     rng = random.Random(8)
     edge = [0, 1, 2, Q - 1, Q - 2, 2**255, 2**128]
