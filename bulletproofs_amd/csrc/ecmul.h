@@ -79,6 +79,45 @@ BP_HD xyzz ec_mul_glv(const affine& P, const fq& k, xyzz* tab) {
     return acc;
 }
 
+// One quarter of k * P for latency-bound callers (few points, every lane of the wave free): slice = half + 2 * part,
+// half selects the GLV component (k1 on P, k2 on lambda P), part the window range (0: windows 0..16, 1: windows 17..32 on
+// the base 2^68 * P_half).  The four slices of a point run in four lanes and are summed by the caller's lane tree:
+// the longest lane does 68 + 60 doublings and 16 additions instead of 128 doublings and 66 additions.
+#define ECMUL_SPLIT_W 17
+BP_HD xyzz ec_mul_glv_slice(const affine& P, const fq& k, int slice, xyzz* tab) {
+    if (affine_is_inf(P)) return xyzz_inf();
+    fq k1, k2;
+    bool n1, n2;
+    fq_glv_split(k, k1, n1, k2, n2);
+    const int half = slice & 1, part = slice >> 1;
+    const fq kk = half ? k2 : k1;
+    const bool neg = half ? n2 : n1;
+    affine Ph = P;
+    if (half) Ph.x = fp_mul(P.x, fp_beta());
+    const int w_lo = part ? ECMUL_SPLIT_W : 0, w_hi = part ? ECMUL_WINS : ECMUL_SPLIT_W;
+    xyzz base = xyzz_from_affine(Ph);
+    if (part) base = xyzz_dbl_n(base, 4 * w_lo);
+    tab[0] = base;
+    xyzz t = xyzz_dbl(base);
+    tab[1] = t;
+    for (int i = 2; i < ECMUL_NT; i++) {
+        xyzz_add(t, base);
+        tab[i] = t;
+    }
+    const uint64_t cm = ecmul_carry_mask(kk);
+    xyzz acc = xyzz_inf();
+    for (int w = w_hi - 1; w >= w_lo; w--) {
+        if (w != w_hi - 1) acc = xyzz_dbl_n(acc, 4);
+        const int d = ecmul_digit(kk, cm, w);
+        if (d != 0) {
+            xyzz e = tab[(d < 0 ? -d : d) - 1];
+            if ((d < 0) != neg) e.Y = fp_neg(e.Y);
+            xyzz_add(acc, e);
+        }
+    }
+    return acc;
+}
+
 // Interleaved (Straus) form for several points in ONE lane: sum_j k_j * P_j with a single chain of
 // 128 doublings shared by all of them (each extra point costs only its 66 window additions).  Used by
 // the batched verifier when a lane owns more than one proof-specific point.

@@ -8,7 +8,7 @@
 //   job j = sum over its SPARSE generator terms (gidx[t], scalar[t])  +  sum over its extra points
 //   k_fb_acc   grid (nblk + nxblk, njobs): blocks < nblk stride over the job's (term, window) items -
 //              one table gather + one mixed addition each, no doublings; blocks >= nblk multiply the
-//              job-specific points (GLV ladder, one lane each); LDS tree -> one XYZZ partial per block
+//              job-specific points (GLV ladder, four lanes each); LDS tree -> one XYZZ partial per block
 //   k_fb_final one block per job: sum of the partials, ONE inversion, canonical x||y bytes
 // The scalars of the generator terms arrive as window digits (k_mb_digits of msm_batch.hip).
 #include <hip/hip_runtime.h>
@@ -62,8 +62,11 @@ __global__ __launch_bounds__(FB_T) void k_fb_acc(const affine_mem* __restrict__ 
         const uint32_t x0 = xoff[job], x1 = xoff[job + 1];
         const int xb = blk - nblk;
         xyzz* tab = vartab + (((size_t)job * nxblk + xb) * FB_T + tid) * ECMUL_NT;
-        for (uint32_t v = x0 + (uint32_t)xb * FB_T + tid; v < x1; v += (uint32_t)nxblk * FB_T) {
-            xyzz r = ec_mul_glv(affine_load(xpts[v]), fq_from_be_reduce(xsc_be + 32 * (size_t)v), tab);
+        // four lanes per job-specific point (ec_mul_glv_slice): these calls wait for the result, so the length of the
+        // longest lane is what counts
+        const int slice = tid & 3;
+        for (uint32_t v = x0 + (uint32_t)(xb * FB_T + tid) / 4; v < x1; v += (uint32_t)nxblk * (FB_T / 4)) {
+            xyzz r = ec_mul_glv_slice(affine_load(xpts[v]), fq_from_be_reduce(xsc_be + 32 * (size_t)v), slice, tab);
             xyzz_add(acc, r);
         }
     }

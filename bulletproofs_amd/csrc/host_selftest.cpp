@@ -103,6 +103,16 @@ void bpt_ec_mul_glv(uint8_t* out, const uint8_t* a, const uint8_t* k) {
     xyzz r = ec_mul_glv(affine_from_be64(a), fq_from_be_reduce(k), tab);
     affine_to_be64(out, xyzz_to_affine(r));
 }
+// the four lane-slices of ec_mul_glv_slice summed: must equal k * a
+void bpt_ec_mul_glv_sliced(uint8_t* out, const uint8_t* a, const uint8_t* k) {
+    xyzz tab[ECMUL_NT];
+    xyzz acc = xyzz_inf();
+    for (int s = 0; s < 4; s++) {
+        xyzz r = ec_mul_glv_slice(affine_from_be64(a), fq_from_be_reduce(k), s, tab);
+        xyzz_add(acc, r);
+    }
+    affine_to_be64(out, xyzz_to_affine(acc));
+}
 // 2^(k+1) * a: one XYZZ doubling (so ZZ != 1) followed by the Jacobian k-fold doubling chain
 void bpt_ec_dbl_n(uint8_t* out, const uint8_t* a, int k) {
     xyzz r = xyzz_dbl(xyzz_from_affine(affine_from_be64(a)));

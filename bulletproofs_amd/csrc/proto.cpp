@@ -197,7 +197,7 @@ int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_i
     int nblk = (int)((max_t * (size_t)W + 255) / 256);
     if (nblk < 1) nblk = 1;
     if (nblk > 128) nblk = 128;
-    const int nxblk = (int)((max_x + 255) / 256);
+    const int nxblk = (int)((4 * max_x + 255) / 256);  // four lanes per job-specific point (ec_mul_glv_slice)
     if (nxblk > 64 || nt >= ((size_t)1 << 31) || nx >= ((size_t)1 << 31)) {
         set_error_msg("internal: fixed-table MSM job too large");
         return BP_EINVAL;

@@ -187,6 +187,11 @@ def test_ec(L, oracle_c):
         o = ctypes.create_string_buffer(64)
         L.bpt_ec_mul_glv_multi(o, b"".join(ec.enc64(p) for p in ps), b"".join(b32(k) for k in ks), cnt)
         assert ec.dec64(o.raw) == oracle_c.msm_naive(ps, ks, None), cnt
+    # the four lane-slices of the latency-path ladder (ec_mul_glv_slice) add up to k * P
+    for a in pts[:5]:
+        for k in [0, 1, 2, Q - 1, Q - 2, 1 << 68, (1 << 68) - 1, 1 << 128, (1 << 129) - 1, 15, 16, 8, 9] + [rng.randrange(Q) for _ in range(12)]:
+            assert p2(L.bpt_ec_mul_glv_sliced, a, b32(k)) == oracle_c.mul(a, k), hex(k)
+            assert p2(L.bpt_ec_mul_glv, a, b32(k)) == oracle_c.mul(a, k), hex(k)
     assert p2(L.bpt_ec_madd, None, pts[0]) == pts[0]
     assert p2(L.bpt_ec_mul, pts[0], b32(Q)) is None
     a = pts[0]
