@@ -269,6 +269,12 @@ int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scal
         HIPCHK(launch_msm_horner((const xyzz*)ctx->wsum.p, 1, 1, d_init, d_res, d_res_be, st), "horner");
         return BP_OK;
     }
+    // tiny MSMs: four lanes per point in one workgroup (k_msm_tiny); forced paths / window widths keep the general pipeline
+    if (n <= msm_tiny_max() && ctx->msm_path == 0 && ctx->forced_c == 0 && !getenv("BP_MSM_PATH") && !getenv("BP_MSM_C")) {
+        if ((rc = ctx->partial.reserve(msm_tiny_scratch_bytes())) != BP_OK) return rc;
+        HIPCHK(launch_msm_tiny(d_points, d_scalars_be, n, d_init, (xyzz*)ctx->partial.p, d_res, d_res_be, st), "msm tiny");
+        return BP_OK;
+    }
     int c = 0, W = 0;
     if ((rc = msm_windows_on_device(ctx, d_points, d_scalars_be, n, 0, &c, &W)) != BP_OK) return rc;
     HIPCHK(launch_msm_horner((const xyzz*)ctx->wsum.p, W, c, d_init, d_res, d_res_be, st), "horner");

@@ -23,6 +23,10 @@ hipError_t launch_msm_slice(const affine_mem* pts, const affine_mem* lam, size_t
                             int W, int S, int T, xyzz* partial, hipStream_t st);
 hipError_t launch_msm_reduce_slices(const xyzz* partial, int S, int W, xyzz* wsum, hipStream_t st);
 hipError_t launch_msm_reduce_parts(const xyzz* parts, int G, int W, xyzz* wsum, hipStream_t st);
+size_t msm_tiny_max();
+size_t msm_tiny_scratch_bytes();
+hipError_t launch_msm_tiny(const affine_mem* pts, const uint8_t* scalars_be, size_t n, const affine_mem* init, xyzz* tabs, affine_mem* out_limbs,
+                           uint8_t* out_be, hipStream_t st);
 hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine_mem* init, affine_mem* out_limbs, uint8_t* out_be, hipStream_t st);
 
 

@@ -311,6 +311,51 @@ __global__ __launch_bounds__(64) void k_msm_reduce_parts(const xyzz* __restrict_
     if (tid == 0) wsum[w] = red[0];
 }
 
+// Tiny MSMs (n <= 64: the reference's two- to ten-term folds such as T1 = t1 G + tau1 H, range_proof.rs:168, or the
+// eq. (65) sides, :337-354): one workgroup, four lanes per point (ec_mul_glv_slice: GLV half x window range), one LDS
+// tree, the division-step inversion.  No buckets, no window sums: the call is pure latency and the longest lane
+// (128 doublings + 16 additions) is the floor for a variable base.
+#define TINY_MAX 64
+__global__ __launch_bounds__(256) void k_msm_tiny(const affine_mem* __restrict__ pts, const uint8_t* __restrict__ scalars_be, int n,
+                                                  const affine_mem* __restrict__ init, xyzz* __restrict__ tabs, affine_mem* __restrict__ out_limbs,
+                                                  uint8_t* __restrict__ out_be) {
+    __shared__ xyzz red[256];
+    const int tid = threadIdx.x, v = tid >> 2, slice = tid & 3;
+    xyzz acc = xyzz_inf();
+    if (v < n) acc = ec_mul_glv_slice(affine_load(pts[v]), fq_from_be_reduce(scalars_be + 32 * (size_t)v), slice, tabs + (size_t)tid * ECMUL_NT);
+    red[tid] = acc;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) {
+            xyzz a = red[tid];
+            xyzz o = red[tid + off];
+            xyzz_add(a, o);
+            red[tid] = a;
+        }
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    xyzz r = red[0];
+    if (init) xyzz_madd(r, affine_load(*init));
+    affine_mem m = affine_store(xyzz_to_affine_var(r));
+    if (out_limbs) *out_limbs = m;
+    if (out_be) {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(out_be);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            dst[7 - k] = __builtin_bswap32(m.x.w[k]);
+            dst[15 - k] = __builtin_bswap32(m.y.w[k]);
+        }
+    }
+}
+size_t msm_tiny_max() { return TINY_MAX; }
+size_t msm_tiny_scratch_bytes() { return (size_t)256 * ECMUL_NT * sizeof(xyzz); }
+hipError_t launch_msm_tiny(const affine_mem* pts, const uint8_t* scalars_be, size_t n, const affine_mem* init, xyzz* tabs, affine_mem* out_limbs,
+                           uint8_t* out_be, hipStream_t st) {
+    hipLaunchKernelGGL(k_msm_tiny, dim3(1), dim3(256), 0, st, pts, scalars_be, (int)n, init, tabs, out_limbs, out_be);
+    return hipGetLastError();
+}
+
 // result = init + sum_w 2^(c*w) wsum[w]  (Horner, one lane: the doubling chain is inherently serial),
 // normalised to the canonical affine element and written as 64 big-endian bytes.
 __global__ __launch_bounds__(64) void k_msm_horner(const xyzz* __restrict__ wsum, int W, int c, const affine_mem* __restrict__ init, affine_mem* __restrict__ out_limbs,
