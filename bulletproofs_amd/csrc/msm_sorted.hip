@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64) void k_srt_horner_part(xyzz* __restrict__ wsum,
 // buckets only needs every partial that belongs to one of them - Bk[b] (the run that starts inside a segment)
 // and the Pseg[t] of every segment that starts inside the bucket - in any order.  One 256-lane workgroup per
 // output: o < LO -> C_o = sum_hi bucket[hi*LO + o];  o >= LO -> R_(o-LO) = sum_lo bucket[(o-LO)*LO + lo].
-// A row's segments are one contiguous range; a column gives each of its HI buckets 256/HI lanes, and buckets
+// A row's segments are one contiguous range; a column gives each of its HI buckets T/HI lanes (at least one), and buckets
 // with many segments (the short top window, skewed scalars) are summed by the whole workgroup afterwards.
 // Depth: ~2-3 additions per lane + an 8-level LDS tree, whatever the bucket sizes are.
 __global__ __launch_bounds__(256) void k_srt_rowcol2(const uint32_t* __restrict__ bstart, const xyzz* __restrict__ Bk,
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_srt_rowcol2(const uint32_t* __restrict_
     __builtin_amdgcn_s_setprio(3);  // latency-bound: issue ahead of the co-resident accumulation waves
     __shared__ uint32_t big_t0[256], big_t1[256];
     __shared__ uint32_t nbig;
-    const int tid = threadIdx.x, w = w0 + blockIdx.y, o = blockIdx.x;
+    const int tid = threadIdx.x, T = blockDim.x, w = w0 + blockIdx.y, o = blockIdx.x;  // T = 64, 128 or 256 lanes per output
     const int stride = (1 << lo_bits) + (NB >> lo_bits);
     const uint32_t* bs = bstart + (size_t)w * (NB + 1);
     int NBe;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_srt_rowcol2(const uint32_t* __restrict_
     __syncthreads();
     if (o >= LO) {
         const int b0 = (o - LO) * LO;
-        for (int i = tid; i < LO; i += 256) {
+        for (int i = tid; i < LO; i += T) {
             const uint32_t s = bs[b0 + i], e = bs[b0 + i + 1];
             if (e > s && (s % uL)) {
                 xyzz v = B[b0 + i];
@@ -262,13 +262,13 @@ __global__ __launch_bounds__(256) void k_srt_rowcol2(const uint32_t* __restrict_
             }
         }
         const uint32_t t0 = (bs[b0] + uL - 1) / uL, t1 = (bs[b0 + LO] + uL - 1) / uL;
-        for (uint32_t t = t0 + tid; t < t1; t += 256) {
+        for (uint32_t t = t0 + tid; t < t1; t += T) {
             xyzz v = P[t];
             xyzz_add(acc, v);
         }
     } else {
-        const int Q = HI >= 256 ? 1 : 256 / HI;  // lanes per bucket
-        for (int h0 = 0; h0 < HI; h0 += 256) {
+        const int Q = HI >= T ? 1 : T / HI;  // lanes per bucket
+        for (int h0 = 0; h0 < HI; h0 += T / Q) {
             const int hi = h0 + tid / Q, sub = tid % Q;
             if (hi < HI) {
                 const int b = hi * LO + o;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_srt_rowcol2(const uint32_t* __restrict_
                         xyzz_add(acc, v);
                     }
                     const uint32_t t0 = (s + uL - 1) / uL, t1 = (e + uL - 1) / uL;
-                    if (t1 - t0 <= (uint32_t)(4 * Q)) {
+                    if (t1 - t0 <= (uint32_t)(4 * Q < 8 ? 8 : 4 * Q)) {
                         for (uint32_t t = t0 + sub; t < t1; t += Q) {
                             xyzz v = P[t];
                             xyzz_add(acc, v);
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_srt_rowcol2(const uint32_t* __restrict_
             const uint32_t nq = nbig;
             for (uint32_t q = 0; q < nq; q++) {
                 const uint32_t t1 = big_t1[q];
-                for (uint32_t t = big_t0[q] + tid; t < t1; t += 256) {
+                for (uint32_t t = big_t0[q] + tid; t < t1; t += T) {
                     xyzz v = P[t];
                     xyzz_add(acc, v);
                 }
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void k_srt_rowcol2(const uint32_t* __restrict_
     }
     red[tid] = acc;
     __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
+    for (int off = T / 2; off >= 1; off >>= 1) {
         if (tid < off) {
             xyzz v = red[tid];
             xyzz u = red[tid + off];
@@ -340,8 +340,12 @@ static void srt_acc_windows(const affine_mem* pts, const affine_mem* lam, size_t
 static hipError_t srt_reduce_windows(const SortedPlan& pl, const SortedBufs& b, int w0, int nw, xyzz* wsum, hipStream_t st) {
     const int NB = pl.NB;
     const int nout = (1 << pl.lo_bits) + (NB >> pl.lo_bits);
-    hipLaunchKernelGGL(k_srt_rowcol2, dim3((unsigned)nout, (unsigned)nw), dim3(256), 0, st, b.bstart, b.Bk, b.Pseg, NB, pl.L, pl.nseg, pl.lo_bits,
-                       w0, b.RC);
+    // lanes per output: 256 measured best at 2^20 and 2^22 (128 equal, 64 loses 12 %: the longer serial part per lane
+    // costs more than the two tree levels it saves; gpurun sweep of BP_MSM_RC_T)
+    int T = 256;
+    if (const char* e = getenv("BP_MSM_RC_T")) T = atoi(e) == 64 || atoi(e) == 128 || atoi(e) == 256 ? atoi(e) : T;
+    hipLaunchKernelGGL(k_srt_rowcol2, dim3((unsigned)nout, (unsigned)nw), dim3((unsigned)T), 0, st, b.bstart, b.Bk, b.Pseg, NB, pl.L, pl.nseg,
+                       pl.lo_bits, w0, b.RC);
     hipLaunchKernelGGL(k_srt_window, dim3((unsigned)nw), dim3(256), 0, st, b.bstart, b.RC, NB, pl.lo_bits, w0, wsum);
     return hipGetLastError();
 }

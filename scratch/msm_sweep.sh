@@ -8,22 +8,11 @@ for l in sys.stdin:
         d=json.loads(l); print(d['ms_per_step'], d['value'], d['config']['result'][:16], d['two_in_flight']['value'])
     elif 'amdgpu.ids' not in l: print(l.rstrip()[:300])
 " || exit 1; }
-export BP_MSM_PRESORT=0
-run BP_MSM_GROUPS=6,3
-run BP_MSM_GROUPS=7,2
-run BP_MSM_GROUPS=6,2,1
-run BP_MSM_GROUPS=5,3,1
-run BP_MSM_GROUPS=4,3,2
-run BP_MSM_GROUPS=6,3 BP_MSM_L=48
-run BP_MSM_GROUPS=6,3 BP_MSM_L=40
-run BP_MSM_GROUPS=6,3 BP_MSM_CH=32768
-run BP_MSM_GROUPS=5,4 BP_MSM_L=48
+run BP_MSM_RC_T=256
+run BP_MSM_RC_T=128
+run BP_MSM_RC_T=64
+run BP_X=auto
 export LOG2=22
-run BP_MSM_GROUPS=9
-run BP_MSM_GROUPS=5,4
-run BP_MSM_GROUPS=6,3
-run BP_MSM_GROUPS=4,3,2
-export LOG2=18
-run BP_MSM_GROUPS=99
-run BP_MSM_GROUPS=5,4
-run BP_MSM_GROUPS=6,3
+run BP_MSM_RC_T=256
+run BP_MSM_RC_T=64
+run BP_X=auto
