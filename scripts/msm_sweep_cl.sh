@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts_msm_sweep.sh "<c list>" "<L list>" [log2n]   -> per-kernel average times of the raw MSM bench under rocprofv3
+# usage: scripts/msm_sweep_cl.sh "<c list>" "<L list>" [log2n]   -> per-kernel average times of the raw MSM bench under rocprofv3
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 LG=${3:-20}
 for c in $1; do for L in $2; do
