@@ -42,6 +42,27 @@ PEAK_MAD32_PER_S = 31.2e12
 PMC_TRAFFIC_BYTES_DEFAULT = 144.93e6 * 64 + 36.81e6 * 64 + 19.64e6 * 32
 
 
+# Rehearsal of the multi-rank path on a ONE-GPU box (BENCH_REHEARSAL=1 under torch.distributed.run): every rank uses
+# GPU 0 and the collectives go over gloo with host tensors.  Never used by the driver's runs (one rank per GPU, RCCL).
+REHEARSAL = os.environ.get("BENCH_REHEARSAL") == "1"
+
+
+def dist_setup(world, local_rank):
+    import torch
+    import torch.distributed as dist
+    if REHEARSAL:
+        local_rank = 0
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if REHEARSAL:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    return local_rank, torch.device("cuda", local_rank), (torch.device("cpu") if REHEARSAL else torch.device("cuda", local_rank))
+
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,11 +137,7 @@ def bench_msm(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_rank, dev, cdev = dist_setup(world, local_rank)
     N = 1 << args.msm_log2
     lo, hi = bt.shard_range(N, rank, world)
     n = hi - lo
@@ -147,7 +164,7 @@ def bench_msm(args):
         if world == 1:
             return ctx.msm_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
         return bt.msm_sharded(N, lambda lo_, hi_: ctx.msm_partial_device(d_pts.data_ptr(), d_sc.data_ptr(), hi_ - lo_, cwin),
-                              lambda parts, g: ctx.msm_combine(parts, g, cwin), dev)
+                              lambda parts, g: ctx.msm_combine(parts, g, cwin), cdev)
 
     for _ in range(args.warmup):
         res = step()
@@ -162,7 +179,7 @@ def bench_msm(args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # Throughput with two contexts in flight (one GPU only): two host threads, one bp_ctx each, every call still one
@@ -345,13 +362,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libbpmsm has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_rank, dev, cdev = dist_setup(world, local_rank)
 
     batch = load_batch()
     P = args.proofs_per_gpu
@@ -405,7 +418,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -464,7 +477,7 @@ def main():
         ctx_b.close()
         ctx.set_msm_pipeline(0)
         if world > 1:
-            t = torch.tensor([dt_rlc], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt_rlc], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_rlc = float(t.item())
         rlc = {"value": world * P * args.steps / dt_rlc, "unit": "proofs/s", "ms_per_step": dt_rlc / args.steps * 1e3, "contexts_in_flight": nthr,
