@@ -40,16 +40,33 @@ static int pick_table_window(int np) {
 
 extern "C" {
 
+static int gens_create_locked(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t nm, const uint8_t G_xy[64], const uint8_t H_xy[64], int c,
+                              bp_gens** out, bool* oom);
+
 int bp_gens_create(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t nm, const uint8_t G_xy[64], const uint8_t H_xy[64],
                    int window_bits, bp_gens** out) {
     if (!ctx || !out || !g_xy || !h_xy || !G_xy || !H_xy || nm == 0 || nm > (1u << 20)) return BP_EINVAL;
     *out = nullptr;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    hipStream_t st = ctx->stream;
-    int np = (int)(2 * nm + 2);
+    const int np = (int)(2 * nm + 2);
     int c = window_bits ? window_bits : pick_table_window(np);
     if (c < 2 || c > BP_MAX_TABLE_WINDOW) return BP_EINVAL;
+    // automatic window: the free-memory reading can be stale (another process building its table on the same GPU), so an
+    // out-of-memory build is retried with a narrower window instead of failing
+    for (;;) {
+        bool oom = false;
+        int rc = gens_create_locked(ctx, g_xy, h_xy, nm, G_xy, H_xy, c, out, &oom);
+        if (rc == BP_OK || window_bits || !oom || c <= 8) return rc;
+        (void)hipGetLastError();
+        c -= 2;
+    }
+}
+
+static int gens_create_locked(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t nm, const uint8_t G_xy[64], const uint8_t H_xy[64], int c,
+                              bp_gens** out, bool* oom) {
+    hipStream_t st = ctx->stream;
+    int np = (int)(2 * nm + 2);
     int W = 256 / c + 1, NB = 1 << (c - 1);
     bp_gens* g = new bp_gens();
     g->device = ctx->device;
@@ -83,6 +100,7 @@ int bp_gens_create(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t
         e = (expr);                         \
         if (e != hipSuccess) {              \
             set_error("bp_gens_create", e); \
+            if (e == hipErrorOutOfMemory) *oom = true; \
             rc = BP_EHIP;                   \
         }                                   \
     }
