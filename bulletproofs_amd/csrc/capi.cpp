@@ -128,6 +128,7 @@ SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
     while (pl.L < 256 && (size_t)pl.L * 8 <= n2 / (size_t)pl.NB) pl.L *= 2;
     while (pl.L > 4 && (size_t)pl.W * n2 / pl.L < 65536) pl.L /= 2;
     if (const char* e = getenv("BP_MSM_L")) pl.L = atoi(e) > 0 ? atoi(e) : 32;
+    pl.L = (pl.L + 7) & ~7;  // k_srt_acc reads the sorted entries in aligned 64-byte lines (8 entries)
     pl.nseg = (int)((pl.npad + pl.L - 1) / pl.L);
     pl.lo_bits = c / 2;  // LO = 2^lo_bits, HI = NB / LO; LO + HI <= 256 for c <= 15
     if (pl.lo_bits > c - 1) pl.lo_bits = c - 1;

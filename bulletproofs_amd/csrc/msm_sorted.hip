@@ -129,23 +129,34 @@ __global__ __launch_bounds__(256, 2) void k_srt_acc(const affine_mem* __restrict
     xyzz acc = xyzz_inf();
     int cur = (int)E[j0].y;
     bool atstart = true;
-    for (uint32_t j = j0; j < j1; j++) {
-        const uint2 ev = E[j];
-        int b = (int)ev.y;
-        if (b != cur) {
-            if (atstart)
-                Pseg[(size_t)w * nseg + t] = acc;
-            else
-                Bk[(size_t)w * NB + cur] = acc;
-            acc = xyzz_inf();
-            cur = b;
-            atstart = false;
+    // Entries are read one 64-byte line (8 entries, four 16-byte loads) at a time; j0 is a multiple of 8 and the window's
+    // array 64-byte aligned.  With one 8-byte load per iteration the line was fetched again for every entry (the point
+    // gathers sweep the caches in between): TCC_EA read requests 27.5 M per launch against 10.6 M algorithmic.
+    for (uint32_t j = j0; j < j1; j += 8) {
+        uint4 q[4];
+#pragma unroll
+        for (int h = 0; h < 4; h++) q[h] = *reinterpret_cast<const uint4*>(E + j + 2 * h);
+        const int cnt = (j1 - j) < 8u ? (int)(j1 - j) : 8;
+#pragma unroll
+        for (int h = 0; h < 8; h++) {
+            if (h < cnt) {
+                const uint32_t e = (h & 1) ? q[h >> 1].z : q[h >> 1].x;
+                const int b = (int)((h & 1) ? q[h >> 1].w : q[h >> 1].y);
+                if (b != cur) {
+                    if (atstart)
+                        Pseg[(size_t)w * nseg + t] = acc;
+                    else
+                        Bk[(size_t)w * NB + cur] = acc;
+                    acc = xyzz_inf();
+                    cur = b;
+                    atstart = false;
+                }
+                size_t v = e & 0x7fffffffu;
+                affine p = affine_load(v < n1 ? pts[v] : lam[v - n1]);
+                if (e >> 31) p.y = fp_neg(p.y);
+                xyzz_madd(acc, p);
+            }
         }
-        uint32_t e = ev.x;
-        size_t v = e & 0x7fffffffu;
-        affine p = affine_load(v < n1 ? pts[v] : lam[v - n1]);
-        if (e >> 31) p.y = fp_neg(p.y);
-        xyzz_madd(acc, p);
     }
     if (atstart)
         Pseg[(size_t)w * nseg + t] = acc;
