@@ -63,6 +63,12 @@ def dist_setup(world, local_rank):
 
 
 
+# HBM-side traffic of one k_srt_acc launch of the 2^20 raw MSM (two launches per MSM: 5 + 4 windows), from the --pmc passes in
+# profiles/r01_msm_pmc_read.csv / r01_msm_pmc_write.csv: TCC_EA0_RDREQ 15.40e6 x 64 B (64-byte point gathers + the sorted
+# entries, one line per 8 entries) + TCC_EA0_WRREQ 1.145e6 x 64 B + 0.182e6 x 32 B (bucket / segment partial sums).
+PMC_TRAFFIC_MSM_ACC_BYTES = 15.40e6 * 64 + 1.145e6 * 64 + 0.182e6 * 32
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,7 +229,9 @@ def bench_msm(args):
             "two_in_flight": two,
             "roofline": {"bound": "valu_int32_mad", "kernel": "whole bp_msm_device pipeline (dominant kernel k_srt_acc)", "achieved": mpts * 1e6 * mad_per_point / world / 1e12,
                          "peak": PEAK_MAD32_PER_S / 1e12, "unit": "TMAD32/s", "frac": mpts * 1e6 * mad_per_point / world / PEAK_MAD32_PER_S,
-                         "traffic": None}}), flush=True)
+                         "traffic": PMC_TRAFFIC_MSM_ACC_BYTES if (args.msm_log2 == 20 and world == 1) else None,
+                         "traffic_unit": "bytes per k_srt_acc launch, two launches per MSM (PMC, profiles/r01_msm_pmc_*.csv); algorithmic: "
+                                         "9.4 M entries x (8 B entry + 64 B point) = 0.68 GB"}}), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
