@@ -89,7 +89,7 @@ MsmPlan plan_msm(size_t n2, int forced_c) {
 }
 
 // Plan of the sorted path (msm_sorted.hip).  Cost model in mixed-add equivalents of whole-GPU
-// throughput: W * (n2 + 3 NB) for bucket accumulation + finalize/row/column additions, plus
+// throughput: W * (n2 + 3 NB) for bucket accumulation + row/column reduction additions, plus
 // W * 146000 for the serial Horner step (one window = a full addition and two coordinate conversions
 // in a lone wave, ~7.7 us, the time in which the GPU retires ~146k mixed additions): small MSMs are
 // latency-bound and want few windows.  c <= 15 (int16 digits, 64 KB LDS histograms).
@@ -121,7 +121,7 @@ SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
     if (pl.nchunks < 1) pl.nchunks = 1;
     pl.npad = (size_t)pl.nchunks * ch;
     // segment length: ~4 segments per average bucket, at least 32 (lanes of a wave then do equal work
-    // and k_srt_finalize adds only a few partial sums per bucket)
+    // and k_srt_rowcol2 adds only a few partial sums per bucket)
     // Small MSMs are latency-bound: shorter segments (more lanes, shorter serial chains) while the grid
     // still has fewer than ~64k lanes.
     pl.L = 32;
