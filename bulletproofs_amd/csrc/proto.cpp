@@ -278,17 +278,21 @@ struct FbBatcher {
     std::vector<Pt*> po;
 
     void flush_locked() {  // mu held; every active thread is waiting
-        std::vector<const FbJob*> all;
-        for (auto* v : pj)
-            for (auto& j : *v) all.push_back(&j);
-        const size_t total = all.size();
-        std::vector<Pt> res(total);
-        static const std::vector<FbJob> none;
-        rc = total ? fbmsm_direct(ctx, g, none, res.data(), &all) : BP_OK;
-        if (rc == BP_OK) {
-            size_t o = 0;
-            for (size_t i = 0; i < pj.size(); i++)
-                for (size_t j = 0; j < pj[i]->size(); j++) po[i][j] = res[o++];
+        try {
+            std::vector<const FbJob*> all;
+            for (auto* v : pj)
+                for (auto& j : *v) all.push_back(&j);
+            const size_t total = all.size();
+            std::vector<Pt> res(total);
+            static const std::vector<FbJob> none;
+            rc = total ? fbmsm_direct(ctx, g, none, res.data(), &all) : BP_OK;
+            if (rc == BP_OK) {
+                size_t o = 0;
+                for (size_t i = 0; i < pj.size(); i++)
+                    for (size_t j = 0; j < pj[i]->size(); j++) po[i][j] = res[o++];
+            }
+        } catch (...) {  // host allocation failure: every proof of this step fails, none is left waiting
+            rc = BP_ENOMEM;
         }
         pj.clear();
         po.clear();
@@ -1464,22 +1468,37 @@ static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
         b.ctx = ctx;
         b.g = gens;
         b.active = (int)cnt;
+        b.pj.reserve(cnt);  // submit() then never allocates
+        b.po.reserve(cnt);
         std::vector<std::thread> thr;
         thr.reserve(cnt);
         for (size_t t = 0; t < cnt; t++) {
             const size_t i = base + t;
-            thr.emplace_back([&, i] {
+            auto body = [&, i] {
                 tl_batcher = &b;
-                size_t len = 0;
-                const uint8_t* sec = secrets_be + i * (size_t)m * 32;
-                const uint8_t* bl = blindings_be + i * (size_t)m * 32;
-                const uint8_t* tp = tapes + i * tape_len;
-                uint8_t* out = proofs_out + i * proof_len;
-                st[i] = wip ? bp_wip_rangeproof_prove(ctx, gens, n_bits, sec, bl, m, tp, tape_len, out, proof_len, &len)
-                            : bp_rangeproof_prove(ctx, gens, n_bits, sec, bl, m, tp, tape_len, out, proof_len, &len);
+                try {
+                    size_t len = 0;
+                    const uint8_t* sec = secrets_be + i * (size_t)m * 32;
+                    const uint8_t* bl = blindings_be + i * (size_t)m * 32;
+                    const uint8_t* tp = tapes + i * tape_len;
+                    uint8_t* out = proofs_out + i * proof_len;
+                    st[i] = wip ? bp_wip_rangeproof_prove(ctx, gens, n_bits, sec, bl, m, tp, tape_len, out, proof_len, &len)
+                                : bp_rangeproof_prove(ctx, gens, n_bits, sec, bl, m, tp, tape_len, out, proof_len, &len);
+                } catch (...) {  // e.g. std::bad_alloc in the host scalar work: this proof fails, the others go on
+                    st[i] = BP_ENOMEM;
+                }
                 tl_batcher = nullptr;
-                b.leave();
-            });
+                b.leave();  // always: the rendezvous counts this thread until it has left
+            };
+            try {
+                thr.emplace_back(body);
+            } catch (...) {  // no more host threads: the proofs of this chunk that did not start fail, nobody waits for them
+                for (size_t u = t; u < cnt; u++) {
+                    st[base + u] = BP_ENOMEM;
+                    b.leave();
+                }
+                break;
+            }
         }
         for (auto& t : thr) t.join();
     }
