@@ -18,7 +18,7 @@ def _pack(points, scalars):
     return b"".join(ec.enc64(p) for p in points), b"".join((k % 2**256).to_bytes(32, "big") for k in scalars)
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 3, 17, 64, 146, 257, 700])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 17, 63, 64, 65, 127, 128, 129, 146, 257, 700])  # 64|65: one-workgroup path ends; 127|128: sorted path begins
 def test_msm_matches_oracle(ctx, oracle_c, n):
     rng = random.Random(1000 + n)
     pts = _rand_points(rng, n, oracle_c)
