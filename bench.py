@@ -34,12 +34,12 @@ MAD32_PER_PROOF_TOTAL = 6.60e6      # + the two fixed-base multiplications y*G, 
 PEAK_MAD32_PER_S = 31.2e12
 # HBM-side traffic of one k_bpv_msm launch at the default configuration (65536 proofs, auto lanes, 20-bit table
 # windows), from the separate --pmc passes in profiles/r01_pmc_read.csv / r01_pmc_write.csv:
-# TCC_EA0_RDREQ 144.93e6 x 64 B (64-byte gathers of table entries and lane-private window tables, not the
+# TCC_EA0_RDREQ 143.80e6 x 64 B (64-byte gathers of table entries and lane-private window tables, not the
 # 16-B/lane streaming pattern the guide's x2 correction was calibrated on: RDREQ x 64 B already matches the
 # algorithmic gather bytes, 1690 table entries x 64 B per proof + the ~1000 window-table reads, so no doubling)
-# + TCC_EA0_WRREQ 36.81e6 x 64 B + 19.64e6 x 32 B (the lane-private window tables).  12.3 GB in 13.8 ms =
-# 0.88 TB/s, 11 % of the HBM peak: the kernel is VALU-bound.
-PMC_TRAFFIC_BYTES_DEFAULT = 144.93e6 * 64 + 36.81e6 * 64 + 19.64e6 * 32
+# + TCC_EA0_WRREQ 36.73e6 x 64 B + 19.70e6 x 32 B (the lane-private window tables).  12.2 GB in 13.7 ms =
+# 0.89 TB/s, 11 % of the HBM peak: the kernel is VALU-bound.
+PMC_TRAFFIC_BYTES_DEFAULT = 143.80e6 * 64 + 36.73e6 * 64 + 19.70e6 * 32
 
 
 # Rehearsal of the multi-rank path on a ONE-GPU box (BENCH_REHEARSAL=1 under torch.distributed.run): every rank uses

@@ -166,7 +166,7 @@ BP_HD xyzz ec_mul_glv_multi(LoadP loadP, LoadK loadK, int cnt, xyzz* tab, int8_t
         }
     }
     if (valid) {
-        fp inv = fp_inv(run);
+        fp inv = fp_inv_var(run);
         for (int j = cnt - 1; j >= 0; j--) {
             if (!((valid >> j) & 1)) continue;
             xyzz* tj = tab + j * ECMUL_SLOTS;

@@ -427,30 +427,35 @@ BP_HD void fp_s30_update_fg(fp_s30& f, fp_s30& g, const int32_t t[4]) {
     g.v[8] = (int32_t)cg;
 }
 
-BP_HD int32_t fp_s30_p(int i) {  // p = 2^256 - 2^32 - 977 in 30-bit limbs
-    return i == 0 ? 0x3ffffc2f : (i == 1 ? 0x3ffffffb : (i < 8 ? 0x3fffffff : 0xffff));
-}
+// The modulus as 30-bit limbs and its inverse mod 2^30: p here, the group order q in fq.h (s30_mod_q).
+struct s30_mod_p {
+    static BP_HD int32_t limb(int i) {  // p = 2^256 - 2^32 - 977
+        return i == 0 ? 0x3ffffc2f : (i == 1 ? 0x3ffffffb : (i < 8 ? 0x3fffffff : 0xffff));
+    }
+    static BP_HD uint32_t inv30() { return 0x2ddacacfu; }  // p^-1 mod 2^30
+};
 
-// (d, e) <- (u d + v e, q d + r e) / 2^30 mod p, kept in (-2p, p)
-BP_HD void fp_s30_update_de(fp_s30& d, fp_s30& e, const int32_t t[4]) {
-    const uint32_t P_INV30 = 0x2ddacacfu;  // p^-1 mod 2^30
+// (d, e) <- (u d + v e, q d + r e) / 2^30 mod M, kept in (-2M, M)
+template <class M>
+BP_HD void s30_update_de(fp_s30& d, fp_s30& e, const int32_t t[4]) {
+    const uint32_t M_INV30 = M::inv30();
     const int32_t u = t[0], v = t[1], q = t[2], r = t[3];
     const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
     int32_t md = (u & sd) + (v & se);
     int32_t me = (q & sd) + (r & se);
     int64_t cd = (int64_t)u * d.v[0] + (int64_t)v * e.v[0];
     int64_t ce = (int64_t)q * d.v[0] + (int64_t)r * e.v[0];
-    md -= (int32_t)((P_INV30 * (uint32_t)cd + (uint32_t)md) & 0x3fffffffu);
-    me -= (int32_t)((P_INV30 * (uint32_t)ce + (uint32_t)me) & 0x3fffffffu);
-    cd += (int64_t)fp_s30_p(0) * md;
-    ce += (int64_t)fp_s30_p(0) * me;
+    md -= (int32_t)((M_INV30 * (uint32_t)cd + (uint32_t)md) & 0x3fffffffu);
+    me -= (int32_t)((M_INV30 * (uint32_t)ce + (uint32_t)me) & 0x3fffffffu);
+    cd += (int64_t)M::limb(0) * md;
+    ce += (int64_t)M::limb(0) * me;
     cd >>= 30;
     ce >>= 30;
 #pragma unroll
     for (int i = 1; i < 9; i++) {
         const int64_t di = d.v[i], ei = e.v[i];
-        cd += (int64_t)u * di + (int64_t)v * ei + (int64_t)fp_s30_p(i) * md;
-        ce += (int64_t)q * di + (int64_t)r * ei + (int64_t)fp_s30_p(i) * me;
+        cd += (int64_t)u * di + (int64_t)v * ei + (int64_t)M::limb(i) * md;
+        ce += (int64_t)q * di + (int64_t)r * ei + (int64_t)M::limb(i) * me;
         d.v[i - 1] = (int32_t)(cd & 0x3fffffff);
         e.v[i - 1] = (int32_t)(ce & 0x3fffffff);
         cd >>= 30;
@@ -460,18 +465,19 @@ BP_HD void fp_s30_update_de(fp_s30& d, fp_s30& e, const int32_t t[4]) {
     e.v[8] = (int32_t)ce;
 }
 
-BP_HD fp fp_inv_var(const fp& a) {
-    const fp_words aw = fp_to_words(a);  // canonical value in [0, p)
+// x^-1 mod M for a canonical x in [0, M) given and returned as 8 little-endian 32-bit words; 0 -> 0.
+template <class M>
+BP_HD void s30_inv_words(const uint32_t aw[8], uint32_t rw[8]) {
     fp_s30 f, g, d, e;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-        f.v[i] = fp_s30_p(i);
+        f.v[i] = M::limb(i);
         d.v[i] = 0;
         e.v[i] = 0;
         // bits [30 i, 30 i + 30) of the 256-bit value
         const int bit = 30 * i, w = bit >> 5, sh = bit & 31;
-        uint64_t two = aw.w[w];
-        if (w + 1 < 8) two |= (uint64_t)aw.w[w + 1] << 32;
+        uint64_t two = aw[w];
+        if (w + 1 < 8) two |= (uint64_t)aw[w + 1] << 32;
         g.v[i] = (int32_t)((uint32_t)(two >> sh) & 0x3fffffffu);
     }
     e.v[0] = 1;
@@ -484,10 +490,10 @@ BP_HD fp fp_inv_var(const fp& a) {
         if (gz == 0) break;
         int32_t t[4];
         delta = fp_divsteps30(delta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
-        fp_s30_update_de(d, e, t);
+        s30_update_de<M>(d, e, t);
         fp_s30_update_fg(f, g, t);
     }
-    // f = +-1: x^-1 = f * d.  Normalise d from (-2p, p) to [0, p).
+    // f = +-1: x^-1 = f * d.  Normalise d from (-2M, M) to [0, M).
     const bool neg = f.v[8] < 0;
     int64_t c = 0;
     int32_t o[9];
@@ -501,13 +507,13 @@ BP_HD fp fp_inv_var(const fp& a) {
             o[8] = (int32_t)c;  // the top limb keeps the sign
         }
     }
-    for (int pass = 0; pass < 3; pass++) {  // value in (-2p, 2p): add or subtract p until it is in [0, p)
+    for (int pass = 0; pass < 3; pass++) {  // value in (-2M, 2M): add or subtract M until it is in [0, M)
         const bool isneg = o[8] < 0;
-        bool ge = !isneg;  // compare with p from the top limb down
+        bool ge = !isneg;  // compare with M from the top limb down
         if (ge) {
             for (int i = 8; i >= 0; i--) {
-                if (o[i] != fp_s30_p(i)) {
-                    ge = o[i] > fp_s30_p(i);
+                if (o[i] != M::limb(i)) {
+                    ge = o[i] > M::limb(i);
                     break;
                 }
             }
@@ -516,7 +522,7 @@ BP_HD fp fp_inv_var(const fp& a) {
         int64_t cc = 0;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
-            cc += (int64_t)o[i] + (isneg ? (int64_t)fp_s30_p(i) : -(int64_t)fp_s30_p(i));
+            cc += (int64_t)o[i] + (isneg ? (int64_t)M::limb(i) : -(int64_t)M::limb(i));
             if (i < 8) {
                 o[i] = (int32_t)(cc & 0x3fffffff);
                 cc >>= 30;
@@ -525,15 +531,20 @@ BP_HD fp fp_inv_var(const fp& a) {
             }
         }
     }
-    fp_words rw;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         // word k = bits [32 k, 32 k + 32) from the 30-bit limbs
         const int bit = 32 * k, l = bit / 30, sh = bit % 30;
         uint64_t acc = (uint64_t)(uint32_t)o[l] >> sh;
         acc |= (uint64_t)(uint32_t)o[l + 1] << (30 - sh);  // sh <= 14: two limbs cover the word
-        rw.w[k] = (uint32_t)acc;
+        rw[k] = (uint32_t)acc;
     }
+}
+
+BP_HD fp fp_inv_var(const fp& a) {
+    const fp_words aw = fp_to_words(a);  // canonical value in [0, p)
+    fp_words rw;
+    s30_inv_words<s30_mod_p>(aw.w, rw.w);
     return fp_from_words(rw);
 }
 

@@ -37,6 +37,7 @@ void bpt_fqm_add(uint8_t* out, const uint8_t* a, const uint8_t* b) {
 void bpt_fqm_sub(uint8_t* out, const uint8_t* a, const uint8_t* b) {
     fq_to_be(out, fqm_to_fq(fqm_sub(fqm_from_fq(fq_from_be_raw(a)), fqm_from_fq(fq_from_be_raw(b)))));
 }
+void bpt_fqm_inv_var(uint8_t* out, const uint8_t* a) { fq_to_be(out, fqm_to_fq(fqm_inv_var(fqm_from_fq(fq_from_be_raw(a))))); }
 void bpt_fqm_inv(uint8_t* out, const uint8_t* a) { fq_to_be(out, fqm_to_fq(fqm_inv(fqm_from_fq(fq_from_be_raw(a))))); }
 // ((a - b) * (a + b) + a) * b - a : chains of lazily reduced values
 void bpt_fqm_chain(uint8_t* out, const uint8_t* a, const uint8_t* b) {

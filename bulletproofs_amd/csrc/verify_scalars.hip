@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64) void k_bpv_fixinv(size_t nproofs, const xyzz* _
         atomicOr(&bad[pr], 1);
         return;
     }
-    fp inv = fp_inv(fp_mul(a.ZZZ, b.ZZZ));
+    fp inv = fp_inv_var(fp_mul(a.ZZZ, b.ZZZ));
     fp ia = fp_mul(inv, b.ZZZ), ib = fp_mul(inv, a.ZZZ);
     affine r;
     fp zi = fp_mul(a.ZZ, ia);
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ p
         atomicOr(&bad[pr], 1);
         return;
     }
-    fqm inv = fqm_inv(run);
+    fqm inv = fqm_inv_var(run);  // division steps: ~6x fewer instructions than the exponentiation (one lane per proof, latency-bound)
     for (int j = k - 1; j >= 0; j--) {
         fqm xm = cs[CS_XJ + j];
         fqm xi = fqm_mul(inv, pref[1 + j]);
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64) void k_wipv_fixinv(size_t nproofs, const xyzz* 
         atomicOr(&bad[pr], 1);
         return;
     }
-    fixaff[pr * 2] = affine_store(xyzz_to_affine(a));
+    fixaff[pr * 2] = affine_store(xyzz_to_affine_var(a));
 }
 
 // z = H(A, yG)                                                                 :424
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(64) void k_wipv_consts(const uint8_t* __restrict__ 
         atomicOr(&bad[pr], 1);
         return;
     }
-    fqm inv = fqm_inv(run);
+    fqm inv = fqm_inv_var(run);  // division steps: ~6x fewer instructions than the exponentiation (one lane per proof, latency-bound)
     for (int j = k - 1; j >= 0; j--) {
         fqm xm = cs[CS_XJ + j];
         fqm xi = fqm_mul(inv, pref[1 + j]);

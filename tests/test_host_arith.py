@@ -70,6 +70,22 @@ def test_fp_inv_var(L):
         assert call1(L.bpt_fp_inv_var, a) == call1(L.bpt_fp_inv, a)
 
 
+def test_fqm_inv_var(L):
+    """fqm_inv_var (division steps mod the group order q, Montgomery in and out: the batch verifiers' per-proof
+    inversion) against Python's pow and the exponentiation chain: edge, sparse, small and 20000 random values."""
+    rng = random.Random(72)
+    vals = [0, 1, 2, 3, Q - 1, Q - 2, Q - 3, 2**255 % Q, 2**128, 2**29 - 1, 2**30, 2**30 - 1, 2**232, (Q + 1) // 2, (Q - 1) // 2, 2**261 % Q,
+            pow(2, -261, Q)]
+    vals += [1 << k for k in range(0, 256, 7)] + [Q - (1 << k) for k in range(0, 250, 11)]
+    vals += [rng.randrange(1 << k) for k in range(1, 256, 3)]
+    vals += [rng.randrange(Q) for _ in range(20000)]
+    for a in vals:
+        want = pow(a, -1, Q) if a else 0
+        assert call1(L.bpt_fqm_inv_var, a) == want, hex(a)
+    for a in vals[1:60]:
+        assert call1(L.bpt_fqm_inv_var, a) == call1(L.bpt_fqm_inv, a)
+
+
 def test_host_fp64_and_decompress(L):
     """The host-only 4x64-limb base field (hostmath.h Fp64: proof-point decompression of the single-proof verifiers)
     against Python ints, and host_decompress against the portable decompression and the oracle on residues,
