@@ -313,6 +313,10 @@ BP_HD fqm fqm_sub(const fqm& a, const fqm& b) {
 BP_HD fqm fqm_neg(const fqm& a) { return fqm_sub(fqm_zero(), a); }
 
 // plain fq (canonical, < q) -> Montgomery domain, and back to the canonical plain value
+BP_HD fqm fqm_r2() {  // R^2 mod q: fqm_mul(plain limbs, R^2) = Montgomery form
+    const fqm r2 = {{0x09f6ab4bu, 0x1f300d1eu, 0x1c0bd5d8u, 0x0c8ada8cu, 0x11cefa2bu, 0x08b79a0fu, 0x1e697f5eu, 0x00e34de2u, 0x009c7356u}};
+    return r2;
+}
 BP_HD fqm fqm_from_fq(const fq& a) {
     const uint32_t* w = a.v;
     fqm t;
@@ -325,13 +329,40 @@ BP_HD fqm fqm_from_fq(const fq& a) {
     t.v[6] = ((w[5] >> 14) | (w[6] << 18)) & BP_M29Q;
     t.v[7] = ((w[6] >> 11) | (w[7] << 21)) & BP_M29Q;
     t.v[8] = w[7] >> 8;
-    const fqm r2 = {{0x09f6ab4bu, 0x1f300d1eu, 0x1c0bd5d8u, 0x0c8ada8cu, 0x11cefa2bu, 0x08b79a0fu, 0x1e697f5eu, 0x00e34de2u, 0x009c7356u}};
-    return fqm_mul(t, r2);
+    return fqm_mul(t, fqm_r2());
+}
+// a / R mod q (Montgomery reduction alone: the m*q half of fqm_mul, 90 MADs instead of 171); result < q + 1
+BP_HD fqm fqm_redc(fqm a) {
+    uint32_t q[9] = BP_FQM_Q;
+    uint32_t qinv = BP_FQM_QINV;
+#pragma unroll
+    for (int i = 0; i < 9; i++) BP_FQ_OPAQUE(q[i]);
+    BP_FQ_OPAQUE(qinv);
+    uint32_t m[9];
+    fqm r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        acc += a.v[k];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * q[k - i];
+        m[k] = ((uint32_t)acc * qinv) & BP_M29Q;
+        BP_FQ_OPAQUE(m[k]);
+        acc += (uint64_t)m[k] * q[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc += (uint64_t)m[i] * q[k - i];
+        r.v[k - 9] = (uint32_t)acc & BP_M29Q;
+        acc >>= 29;
+    }
+    r.v[8] = (uint32_t)acc;
+    return r;
 }
 BP_HD fq fqm_to_fq(const fqm& a) {
-    fqm u = fqm_zero();
-    u.v[0] = 1;
-    fqm c = fqm_mul(a, u);  // a / R  < q + 1
+    fqm c = fqm_redc(a);  // a / R  < q + 1
     const uint32_t q[9] = BP_FQM_Q;
     fqm_csub(c.v, q);
     const uint32_t* v = c.v;

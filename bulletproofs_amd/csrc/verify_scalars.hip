@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64) void k_bpv_hash2(int k, int m, size_t nproofs, 
 #define CS_XJ 3                        // k : x_j
 #define CS_XINV(k) (3 + (k))           // k : x_j^-1
 #define CS_YINVP(k) (3 + 2 * (k))      // k : y^-(2^t)
-#define CS_ZPOW(k) (3 + 3 * (k))       // m : z^(2+j)
+#define CS_ZPOW(k) (3 + 3 * (k))       // m : z^(2+j) R (times R once more: k_bpv_vec multiplies it by a PLAIN 2^r)
 // split-index tables for k_bpv_vec: i = hi * 2^LO + lo with LO = k/2 low bits and k - LO high bits;
 // s_i = SLO[lo] * SHI[hi], s_i^-1 = s_{nm-1-i} = SLO[~lo] * SHI[~hi], y^-i = YLO[lo] * YHI[hi]
 #define CS_LOBITS(k) ((k) / 2)
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ p
     fqm zsq = fqm_mul(z_m, z_m);
     fqm zp = zsq, sum_z = fqm_zero();
     for (int j = 0; j < m; j++) {
-        cs[CS_ZPOW(k) + j] = zp;
+        cs[CS_ZPOW(k) + j] = fqm_mul(zp, fqm_r2());
         sum_z = fqm_add(sum_z, zp);
         vs[1 + 2 * k + j] = fqm_to_fq(fqm_mul(c_m, zp));    // V_j : c z^(2+j)  :734-736
         zp = fqm_mul(zp, z_m);
@@ -475,10 +475,11 @@ __global__ __launch_bounds__(256) void k_bpv_vec(int n_bits, int m, int k, size_
     fqm sinv = fqm_mul(slo[lom - lo], shi[him - hi]);
     fqm yip = fqm_mul(cs[CS_YLO(k, m) + lo], cs[CS_YHI(k, m) + hi]);
     fqm z_m = cs[CS_Z];
-    fq two_r = fq_zero();
+    // 2^r as PLAIN 29-bit limbs times the pre-scaled constant (z-power times R, Montgomery form): one multiplication
+    fqm two_r = fqm_zero();
     int r = i % n_bits;
-    two_r.v[r >> 5] = 1u << (r & 31);
-    fqm d_i = fqm_mul(fqm_from_fq(two_r), cs[CS_ZPOW(k) + i / n_bits]);
+    two_r.v[r / 29] = 1u << (r % 29);
+    fqm d_i = fqm_mul(two_r, cs[CS_ZPOW(k) + i / n_bits]);
     fqm gs, hs;
     if (wip) {
         gs = fqm_add(fqm_mul(fqm_mul(cs[CS_A], s), yip), z_m);
@@ -668,7 +669,7 @@ __global__ __launch_bounds__(64) void k_wipv_consts(const uint8_t* __restrict__ 
     fqm zsq = fqm_mul(z_m, z_m);
     fqm zp = zsq, sum_z = fqm_zero();
     for (int j = 0; j < m; j++) {
-        cs[CS_ZPOW(k) + j] = fqm_mul(esq_ynm, zp);                  // e^2 y^nm z^(2(j+1)): factor of d_i y^(nm-i) in H_i
+        cs[CS_ZPOW(k) + j] = fqm_mul(fqm_mul(esq_ynm, zp), fqm_r2());                  // e^2 y^nm z^(2(j+1)): factor of d_i y^(nm-i) in H_i
         sum_z = fqm_add(sum_z, zp);
         vs[2 + 2 * k + j] = fqm_to_fq(fqm_mul(mesq_ynm1, zp));      // V_j : -e^2 y^(nm+1) z^(2(j+1))   :568-571
         zp = fqm_mul(zp, zsq);
