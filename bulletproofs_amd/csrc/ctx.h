@@ -89,9 +89,13 @@ struct bp_gens {
     int device = 0;
     size_t nm = 0;
     int np = 0;  // 2nm + 2
+    // table row of the secp256k1 generator, the base of y*G (`Point::generator() * &y`, range_proof.rs:570-571): row 2nm
+    // when the caller's G is the generator (every reference test and bench), else an extra row np after H
+    int ibase = 0;
+    int nrows = 0;  // table rows: np, or np + 1 with the extra generator row
     int c = 0, W = 0, NB = 0;
     bp::affine_mem* d_pts = nullptr;    // g_vec, h_vec, G, H
-    bp::affine_mem* d_table = nullptr;  // [np][W][NB]
+    bp::affine_mem* d_table = nullptr;  // [np (+1 when ibase == np)][W][NB]
     size_t table_bytes = 0;
     std::vector<uint8_t> host_be;       // np * 64 bytes (x||y big-endian), for host-side transcript hashing
 };

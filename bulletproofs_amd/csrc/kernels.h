@@ -66,7 +66,7 @@ size_t bpv_chal_count(int k);
 size_t bpv_cst_count(int k, int m);
 hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
                                       const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fqm* scF, fq* varS, fq* chal,
-                                      fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st);
+                                      fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st, int ibase);
 // rlc_kernels.hip: random-linear-combination batch verification (one MSM for the whole batch)
 hipError_t launch_rlc_weights(const uint8_t* seed32, size_t nproofs, const int* bad, fqm* rho, hipStream_t st);
 hipError_t launch_rlc_var_scalars(int k, int m, size_t nproofs, const fqm* rho, const fq* varS, uint8_t* sc_be, hipStream_t st, int wip = 0);
@@ -80,7 +80,7 @@ hipError_t launch_wipv_decompress(const uint8_t* proofs, size_t proof_len, const
                                   int* bad, hipStream_t st);
 hipError_t launch_wipv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
                                        const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fqm* scF, fq* varS, fq* chal,
-                                       fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st);
+                                       fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st, int ibase);
 size_t bpv_msm_vartab_bytes(int tp, size_t nproofs);
 
 

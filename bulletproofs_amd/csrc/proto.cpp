@@ -222,7 +222,7 @@ int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_i
         h_toff[j] = (uint32_t)t;
         h_xoff[j] = (uint32_t)x;
         for (size_t i = 0; i < jobs[j].gi.size(); i++, t++) {
-            if (jobs[j].gi[i] >= (uint32_t)g->np) {
+            if (jobs[j].gi[i] >= (uint32_t)g->nrows) {
                 set_error_msg("internal: generator index out of range");
                 return BP_EINVAL;
             }
@@ -831,7 +831,7 @@ int bp_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint
     Fq y = Transcript().point(A.b).point(S.b).result_scalar();  // :124
     Pt yG;
     jobs.assign(1, FbJob());
-    jobs[0].gen(iG, y);
+    jobs[0].gen(gens->ibase, y);  // Point::generator() * y, not the caller's G
     RC(fbmsm(ctx, gens, jobs, &yG));  // :126
     if (yG.is_inf()) return BP_EINVAL;
     Fq z = Transcript().point(yG.b).result_scalar();  // :127
@@ -936,7 +936,7 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
     Fq y = Transcript().point(pf.A.b).point(pf.S.b).result_scalar();
     Fq xu = Transcript().bigint32(pf.tau_x_be).bigint32(pf.miu_be).bigint32(pf.tx_be).result_scalar();
     std::vector<FbJob> jobs(2);
-    jobs[0].gen(iG, y);   // base_point * y   (:588)
+    jobs[0].gen(gens->ibase, y);  // Point::generator() * y, not the caller's G   // base_point * y   (:588)
     jobs[1].gen(iG, xu);  // ux = G * x_u     (:657-658)
     Pt yGux[2];
     RC(fbmsm(ctx, gens, jobs, yGux));
@@ -1293,7 +1293,7 @@ int bp_wip_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const 
     std::vector<int> bits = secret_bits(secrets_be, m, n);
     Fq alpha = tp.next();  // :150
     if (!tp.ok) return BP_EINVAL;
-    const size_t iG = 2 * nm, iH = 2 * nm + 1;
+    const size_t iH = 2 * nm + 1;
     std::vector<FbJob> jobs(1);
     for (size_t i = 0; i < nm; i++) {
         if (bits[i])
@@ -1308,7 +1308,7 @@ int bp_wip_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const 
     Fq y = Transcript().point(A.b).result_scalar();  // :167
     Pt yG;
     jobs.assign(1, FbJob());
-    jobs[0].gen(iG, y);
+    jobs[0].gen(gens->ibase, y);  // Point::generator() * y, not the caller's G
     RC(fbmsm(ctx, gens, jobs, &yG));
     if (yG.is_inf()) return BP_EINVAL;
     Fq z = Transcript().point(A.b).point(yG.b).result_scalar();  // :171
@@ -1373,7 +1373,7 @@ int bp_wip_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
     Fq y = Transcript().point(pf.A.b).result_scalar();
     Pt yG;
     std::vector<FbJob> jobs(1);
-    jobs[0].gen(iG, y);
+    jobs[0].gen(gens->ibase, y);  // Point::generator() * y, not the caller's G
     RC(fbmsm(ctx, gens, jobs, &yG));
     if (y.is_zero() || yG.is_inf()) {
         *verdict = BP_VERDICT_MALFORMED;

@@ -38,6 +38,12 @@ static int pick_table_window(int np) {
     return best;
 }
 
+// secp256k1 generator, x || y big-endian
+static const uint8_t kSecpGenerator[64] = {
+    0x79, 0xBE, 0x66, 0x7E, 0xF9, 0xDC, 0xBB, 0xAC, 0x55, 0xA0, 0x62, 0x95, 0xCE, 0x87, 0x0B, 0x07, 0x02, 0x9B, 0xFC, 0xDB, 0x2D, 0xCE,
+    0x28, 0xD9, 0x59, 0xF2, 0x81, 0x5B, 0x16, 0xF8, 0x17, 0x98, 0x48, 0x3A, 0xDA, 0x77, 0x26, 0xA3, 0xC4, 0x65, 0x5D, 0xA4, 0xFB, 0xFC,
+    0x0E, 0x11, 0x08, 0xA8, 0xFD, 0x17, 0xB4, 0x48, 0xA6, 0x85, 0x54, 0x19, 0x9C, 0x47, 0xD0, 0x8F, 0xFB, 0x10, 0xD4, 0xB8};
+
 extern "C" {
 
 static int gens_create_locked(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t nm, const uint8_t G_xy[64], const uint8_t H_xy[64], int c,
@@ -49,7 +55,7 @@ int bp_gens_create(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t
     *out = nullptr;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    const int np = (int)(2 * nm + 2);
+    const int np = (int)(2 * nm + 2) + (memcmp(G_xy, kSecpGenerator, 64) != 0 ? 1 : 0);  // table rows (see bp_gens::ibase)
     int c = window_bits ? window_bits : pick_table_window(np);
     if (c < 2 || c > BP_MAX_TABLE_WINDOW) return BP_EINVAL;
     // automatic window: the free-memory reading can be stale (another process building its table on the same GPU), so an
@@ -66,12 +72,15 @@ int bp_gens_create(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t
 static int gens_create_locked(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t nm, const uint8_t G_xy[64], const uint8_t H_xy[64], int c,
                               bp_gens** out, bool* oom) {
     hipStream_t st = ctx->stream;
-    int np = (int)(2 * nm + 2);
+    const bool own_base = memcmp(G_xy, kSecpGenerator, 64) != 0;
+    int np = (int)(2 * nm + 2) + (own_base ? 1 : 0);  // table rows: g_vec, h_vec, G, H (+ the secp256k1 generator)
     int W = 256 / c + 1, NB = 1 << (c - 1);
     bp_gens* g = new bp_gens();
     g->device = ctx->device;
     g->nm = nm;
-    g->np = np;
+    g->np = (int)(2 * nm + 2);
+    g->ibase = own_base ? (int)(2 * nm + 2) : (int)(2 * nm);
+    g->nrows = np;
     g->c = c;
     g->W = W;
     g->NB = NB;
@@ -86,6 +95,7 @@ static int gens_create_locked(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h
     memcpy(host.data() + nm * 64, h_xy, nm * 64);
     memcpy(host.data() + 2 * nm * 64, G_xy, 64);
     memcpy(host.data() + (2 * nm + 1) * 64, H_xy, 64);
+    if (own_base) memcpy(host.data() + (2 * nm + 2) * 64, kSecpGenerator, 64);
     for (int i = 0; i < np && rc == BP_OK; i++) {
         bool allz = true;
         for (int j = 0; j < 64; j++) allz = allz && host[(size_t)i * 64 + j] == 0;
@@ -133,6 +143,7 @@ static int gens_create_locked(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h
         bp_gens_destroy(g);
         return rc;
     }
+    host.resize((size_t)g->np * 64);
     g->host_be = host;
     *out = g;
     return BP_OK;
@@ -204,10 +215,9 @@ int bp_profile_get(bp_ctx* ctx, int kernel_id, double* total_ms, long* launches)
 }
 
 // argument checks shared by the batch verifiers: BP_EINVAL where the reference asserts (range_proof.rs:556-562)
-static int check_batch_args(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len, const void* d_coms_xy,
-                            size_t nproofs, void* d_verdicts, int* k_out, int wip = 0) {
+// (sizes only: the host-pointer entry points run it BEFORE they read the caller's buffers with these sizes)
+static int check_batch_sizes(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, size_t proof_len, int* k_out, int wip) {
     if (!ctx || !gens || n_bits <= 0 || n_bits > 128 || m <= 0) return BP_EINVAL;
-    if (nproofs && (!d_proofs || !d_coms_xy || !d_verdicts)) return BP_EINVAL;
     size_t nm = (size_t)n_bits * m;
     if (nm != gens->nm || (nm & (nm - 1)) != 0 || gens->device != ctx->device) {
         set_error_msg("n_bits*m must be a power of two and equal the generators' nm (range_proof.rs:556-558)");
@@ -222,7 +232,60 @@ static int check_batch_args(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
     *k_out = k;
     return BP_OK;
 }
+static int check_batch_args(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len, const void* d_coms_xy,
+                            size_t nproofs, void* d_verdicts, int* k_out, int wip = 0) {
+    int rc = check_batch_sizes(ctx, gens, n_bits, m, proof_len, k_out, wip);
+    if (rc != BP_OK) return rc;
+    if (nproofs && (!d_proofs || !d_coms_xy || !d_verdicts)) return BP_EINVAL;
+    return BP_OK;
+}
 
+// Workspaces of one batch verification (device memory beyond the inputs and outputs): the grow-only buffers of the context
+// for the ordinary entry points, slices of the file-scope `scratch` array for the no-allocation entry point.
+struct VerifyWs {
+    affine_mem* pts;   // decompressed proof points + commitments
+    int* bad;          // per-proof malformed flags
+    tdig_t* dig;       // window digits of the 2nm+2 generator scalars
+    fq* var;           // scalars of the proof-specific points
+    fq* chal;          // challenges, then the per-proof constants (cst)
+    xyzz* fixres;      // y*G, x_u*G (projective), then their affine forms
+    xyzz* vartab;      // lane-private window tables of k_bpv_msm
+};
+struct VerifySizes {
+    size_t pts, bad, dig, var, chal, fixres, vartab;
+    int tp;
+    size_t total() const {  // as laid out by carve(): every slice starts on a 256-byte boundary
+        size_t t = 0;
+        for (size_t b : {pts, bad, dig, var, chal, fixres, vartab}) t += (b + 255) / 256 * 256;
+        return t;
+    }
+};
+static VerifySizes verify_ws_sizes(const bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, size_t nproofs, int wip) {
+    const int NPT = (wip ? 3 : 4) + 2 * k + m, NV = (wip ? 2 : 3) + 2 * k + m;
+    VerifySizes z;
+    z.pts = nproofs * NPT * sizeof(affine_mem);
+    z.bad = nproofs * sizeof(int);
+    z.dig = nproofs * (size_t)gens->np * gens->W * sizeof(tdig_t);
+    z.var = nproofs * NV * sizeof(fq);
+    z.chal = nproofs * (bpv_chal_count(k) + bpv_cst_count(k, m)) * sizeof(fq);
+    z.fixres = nproofs * 2 * (sizeof(xyzz) + sizeof(affine_mem));
+    // lanes per proof: fewer lanes share more doubling chains (less work) but need more proofs in
+    // flight to fill 256 CUs x 4 SIMDs x 2 waves
+    int tp = ctx->verify_lanes;
+    if (tp != 2 && tp != 4 && tp != 8 && tp != 16 && tp != 32 && tp != 64) {
+        tp = nproofs >= 65536 ? 2 : (nproofs >= 32768 ? 4 : (nproofs >= 12288 ? 8 : 16));
+        // aggregated proofs (n*m >= 512): the table part dominates and has no per-lane overhead, so take enough
+        // lanes for two waves per SIMD (131072 lanes) even with few proofs in the batch
+        if ((size_t)n_bits * m >= 512)
+            while (tp < 64 && nproofs * (size_t)tp < 131072) tp *= 2;
+    }
+    z.tp = tp;
+    z.vartab = bpv_msm_vartab_bytes(tp, nproofs);
+    return z;
+}
+
+static int verify_batch_launch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, const void* d_proofs, size_t proof_len,
+                               const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip, const VerifyWs& ws, int tp);
 static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, const void* d_proofs, size_t proof_len,
                                       const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip = 0);
 
@@ -240,59 +303,52 @@ int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bi
 static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, const void* d_proofs, size_t proof_len,
                                       const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip) {
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    hipStream_t st = ctx->stream;
-    const int NPT = (wip ? 3 : 4) + 2 * k + m, NV = (wip ? 2 : 3) + 2 * k + m;
+    const VerifySizes z = verify_ws_sizes(ctx, gens, n_bits, m, k, nproofs, wip);
     int rc;
     DevBuf &b_pts = ctx->scratch[0], &b_bad = ctx->scratch[1], &b_dig = ctx->scratch[2], &b_var = ctx->scratch[3], &b_s = ctx->scratch[4];
-    if ((rc = b_pts.reserve(nproofs * NPT * sizeof(affine_mem))) != BP_OK) return rc;
-    if ((rc = b_bad.reserve(nproofs * sizeof(int))) != BP_OK) return rc;
-    if ((rc = b_dig.reserve(nproofs * (size_t)gens->np * gens->W * sizeof(tdig_t))) != BP_OK) return rc;
-    if ((rc = b_var.reserve(nproofs * NV * sizeof(fq))) != BP_OK) return rc;
-    if ((rc = b_s.reserve(nproofs * (bpv_chal_count(k) + bpv_cst_count(k, m)) * sizeof(fq))) != BP_OK) return rc;
-    if ((rc = ctx->fixres.reserve(nproofs * 2 * (sizeof(xyzz) + sizeof(affine_mem)))) != BP_OK) return rc;
-    fq* d_chal = (fq*)b_s.p;
+    if ((rc = b_pts.reserve(z.pts)) != BP_OK) return rc;
+    if ((rc = b_bad.reserve(z.bad)) != BP_OK) return rc;
+    if ((rc = b_dig.reserve(z.dig)) != BP_OK) return rc;
+    if ((rc = b_var.reserve(z.var)) != BP_OK) return rc;
+    if ((rc = b_s.reserve(z.chal)) != BP_OK) return rc;
+    if ((rc = ctx->fixres.reserve(z.fixres)) != BP_OK) return rc;
+    if ((rc = ctx->vartab.reserve(z.vartab)) != BP_OK) return rc;
+    VerifyWs ws{(affine_mem*)b_pts.p, (int*)b_bad.p, (tdig_t*)b_dig.p, (fq*)b_var.p, (fq*)b_s.p, (xyzz*)ctx->fixres.p, (xyzz*)ctx->vartab.p};
+    return verify_batch_launch(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, wip, ws, z.tp);
+}
+
+// the kernels of one batch verification on the context's stream; allocates nothing
+static int verify_batch_launch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, const void* d_proofs, size_t proof_len,
+                               const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip, const VerifyWs& ws, int tp) {
+    hipStream_t st = ctx->stream;
+    fq* d_chal = ws.chal;
     fq* d_cst = d_chal + nproofs * bpv_chal_count(k);
-    xyzz* d_fixres = (xyzz*)ctx->fixres.p;
+    xyzz* d_fixres = ws.fixres;
     affine_mem* d_fixaff = (affine_mem*)(d_fixres + nproofs * 2);
-    HIPCHK(hipMemsetAsync(b_bad.p, 0, nproofs * sizeof(int), st), "memset");
+    HIPCHK(hipMemsetAsync(ws.bad, 0, nproofs * sizeof(int), st), "memset");
     if (ctx->profiling && ctx->prof_n) {  // previous call not collected yet: drain it first
         HIPCHK(hipStreamSynchronize(st), "sync");
         prof_collect(ctx);
     }
     prof_mark(ctx, 0);
     if (wip)
-        HIPCHK(launch_wipv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine_mem*)b_pts.p,
-                                      (int*)b_bad.p, st),
+        HIPCHK(launch_wipv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, ws.pts, ws.bad, st),
                "wipv_decompress");
     else
-        HIPCHK(launch_bpv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine_mem*)b_pts.p,
-                                     (int*)b_bad.p, st),
+        HIPCHK(launch_bpv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, ws.pts, ws.bad, st),
                "bpv_decompress");
     prof_mark(ctx, 1);
     if (wip)
-        HIPCHK(launch_wipv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
-                                           gens->d_table, gens->c, gens->W, (tdig_t*)b_dig.p, nullptr, (fq*)b_var.p, d_chal, d_cst, d_fixres,
-                                           d_fixaff, (int*)b_bad.p, st),
+        HIPCHK(launch_wipv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, ws.pts, gens->d_pts, gens->d_table, gens->c,
+                                           gens->W, ws.dig, nullptr, ws.var, d_chal, d_cst, d_fixres, d_fixaff, ws.bad, st, gens->ibase),
                "wipv_scalars");
     else
-        HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
-                                          gens->d_table, gens->c, gens->W, (tdig_t*)b_dig.p, nullptr, (fq*)b_var.p, d_chal, d_cst, d_fixres,
-                                          d_fixaff, (int*)b_bad.p, st),
+        HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, ws.pts, gens->d_pts, gens->d_table, gens->c,
+                                          gens->W, ws.dig, nullptr, ws.var, d_chal, d_cst, d_fixres, d_fixaff, ws.bad, st, gens->ibase),
                "bpv_scalars");
     prof_mark(ctx, 2);
-    // lanes per proof: fewer lanes share more doubling chains (less work) but need more proofs in
-    // flight to fill 256 CUs x 4 SIMDs x 2 waves
-    int tp = ctx->verify_lanes;
-    if (tp != 2 && tp != 4 && tp != 8 && tp != 16 && tp != 32 && tp != 64) {
-        tp = nproofs >= 65536 ? 2 : (nproofs >= 32768 ? 4 : (nproofs >= 12288 ? 8 : 16));
-        // aggregated proofs (n*m >= 512): the table part dominates and has no per-lane overhead, so take enough
-        // lanes for two waves per SIMD (131072 lanes) even with few proofs in the batch
-        if ((size_t)n_bits * m >= 512)
-            while (tp < 64 && nproofs * (size_t)tp < 131072) tp *= 2;
-    }
-    if ((rc = ctx->vartab.reserve(bpv_msm_vartab_bytes(tp, nproofs))) != BP_OK) return rc;
-    HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_table, gens->c, gens->W, (const tdig_t*)b_dig.p,
-                          (const fq*)b_var.p, (xyzz*)ctx->vartab.p, (const int*)b_bad.p, (uint8_t*)d_verdicts, st, wip),
+    HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, ws.pts, gens->d_table, gens->c, gens->W, ws.dig, ws.var, ws.vartab, ws.bad,
+                          (uint8_t*)d_verdicts, st, wip),
            "bpv_msm");
     prof_mark(ctx, 3);
     if (ctx->profiling) {
@@ -374,7 +430,7 @@ static int verify_batch_rlc_device_impl(bp_ctx* ctx, const bp_gens* gens, int n_
                "wipv_decompress");
         HIPCHK(launch_wipv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
                                            gens->d_table, gens->c, W, nullptr, (fqm*)b_scF.p, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
-                                           (int*)b_bad.p, st),
+                                           (int*)b_bad.p, st, gens->ibase),
                "wipv_scalars");
     } else {
         HIPCHK(launch_bpv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine_mem*)b_pts.p,
@@ -382,7 +438,7 @@ static int verify_batch_rlc_device_impl(bp_ctx* ctx, const bp_gens* gens, int n_
                "bpv_decompress");
         HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
                                           gens->d_table, gens->c, W, nullptr, (fqm*)b_scF.p, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
-                                          (int*)b_bad.p, st),
+                                          (int*)b_bad.p, st, gens->ibase),
                "bpv_scalars");
     }
     HIPCHK(launch_rlc_weights(misc + o_seed, nproofs, (const int*)b_bad.p, (fqm*)b_rho.p, st), "rlc_weights");
@@ -522,12 +578,15 @@ int bp_wip_rangeproof_verify_batch_rlc(bp_ctx* ctx, const bp_gens* gens, int n_b
 }
 static int verify_batch_rlc_host(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
                                  const uint8_t* coms_xy, size_t nproofs, const uint8_t seed[32], uint8_t* verdicts, int* used_fallback, int wip) {
-    if (!ctx || !gens || m <= 0 || !seed) return BP_EINVAL;
+    if (!seed) return BP_EINVAL;
+    int k = 0;
+    int rc = check_batch_sizes(ctx, gens, n_bits, m, proof_len, &k, wip);
+    if (rc != BP_OK) return rc;
     if (used_fallback) *used_fallback = 0;
     if (nproofs == 0) return BP_OK;
     if (!proofs || !coms_xy || !verdicts) return BP_EINVAL;
     void *d_p, *d_c, *d_v;
-    int rc = stage_batch(ctx, proofs, proof_len, coms_xy, m, nproofs, &d_p, &d_c, &d_v);
+    rc = stage_batch(ctx, proofs, proof_len, coms_xy, m, nproofs, &d_p, &d_c, &d_v);
     if (rc != BP_OK) return rc;
     rc = verify_batch_rlc_device_impl(ctx, gens, n_bits, m, d_p, proof_len, d_c, nproofs, seed, d_v, used_fallback, wip);
     if (rc != BP_OK) return rc;
@@ -540,7 +599,8 @@ static int verify_batch_rlc_host(bp_ctx* ctx, const bp_gens* gens, int n_bits, i
 
 int bp_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
                                const uint8_t* coms_xy, size_t nproofs, uint8_t* verdicts) {
-    if (!ctx || !gens || m <= 0) return BP_EINVAL;
+    int k0 = 0;
+    if (int rcs = check_batch_sizes(ctx, gens, n_bits, m, proof_len, &k0, 0)) return rcs;
     if (nproofs == 0) return BP_OK;
     if (!proofs || !coms_xy || !verdicts) return BP_EINVAL;
     void *d_p, *d_c, *d_v;
@@ -556,7 +616,8 @@ int bp_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int
 
 int bp_wip_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proofs, size_t proof_len,
                                    const uint8_t* coms_xy, size_t nproofs, uint8_t* verdicts) {
-    if (!ctx || !gens || m <= 0) return BP_EINVAL;
+    int k0 = 0;
+    if (int rcs = check_batch_sizes(ctx, gens, n_bits, m, proof_len, &k0, 1)) return rcs;
     if (nproofs == 0) return BP_OK;
     if (!proofs || !coms_xy || !verdicts) return BP_EINVAL;
     void *d_p, *d_c, *d_v;

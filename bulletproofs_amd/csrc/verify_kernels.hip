@@ -16,7 +16,6 @@
 // Per-proof verdicts follow `Result<(), Errors>`: 0 = Ok, 3 = RangeProofError, 255 = the proof bytes
 // would not deserialize in the reference (bad point / scalar >= q / zero challenge).
 #include <hip/hip_runtime.h>
-#include <stdlib.h>
 
 #include "ec.h"
 #include "ecmul.h"
@@ -98,7 +97,7 @@ template <int TP, int PPL>
 __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int m, int k, size_t nproofs, const affine_mem* __restrict__ pts,
                                                  const affine_mem* __restrict__ table, int c, int W, const tdig_t* __restrict__ digF,
                                                  const fq* __restrict__ varS, xyzz* __restrict__ vartab, int8_t* __restrict__ vardig,
-                                                 const int* __restrict__ bad, uint8_t* __restrict__ verdicts, int dbg_skip, int wip) {
+                                                 const int* __restrict__ bad, uint8_t* __restrict__ verdicts, int wip) {
     __shared__ xyzz red[256];
     const int tid = threadIdx.x;
     const int lane = tid % TP;
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
     if (active) {
         const int nfw = (2 * nm + 2) * W;
         const tdig_t* dg = digF + pr * (size_t)nfw;
-        for (int idx = lane; idx < ((dbg_skip & 1) ? 0 : nfw); idx += TP) {
+        for (int idx = lane; idx < nfw; idx += TP) {
             int d = dg[idx];
             if (d != 0) {
                 affine e = affine_load(table[(size_t)idx * NB + ((d < 0 ? -d : d) - 1)]);
@@ -127,7 +126,7 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
         const size_t gl = (size_t)blockIdx.x * 256 + tid;
         xyzz* tab = vartab + gl * (PPL * ECMUL_SLOTS);
         int8_t* dig = vardig + gl * (PPL * ECMUL_DIGB);
-        for (int v0 = lane; v0 < ((dbg_skip & 2) ? 0 : NV); v0 += TP * PPL) {
+        for (int v0 = lane; v0 < NV; v0 += TP * PPL) {
             int cnt = (NV - v0 + TP - 1) / TP;
             if (cnt > PPL) cnt = PPL;
             // variable point order: S, L_0.., R_0.., V_0.., T1, T2  ->  index into pts
@@ -190,12 +189,10 @@ size_t bpv_msm_vartab_bytes(int tp, size_t nproofs) {
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
                           const tdig_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st, int wip) {
     unsigned blocks = (unsigned)((nproofs + (256 / tp) - 1) / (256 / tp));
-    const char* e = getenv("BP_DEBUG_SKIP");  // timing experiments only: 1 = skip fixed part, 2 = skip variable part
-    int dbg = e ? atoi(e) : 0;
     int8_t* vardig = reinterpret_cast<int8_t*>(vartab + (size_t)blocks * 256 * bpv_ppl(tp) * ECMUL_SLOTS);
 #define BPV_LAUNCH(TP, PPL)                                                                                                                  \
     hipLaunchKernelGGL((k_bpv_msm<TP, PPL>), dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, vardig, \
-                       bad, verdicts, dbg, wip)
+                       bad, verdicts, wip)
     if (tp == 2)
         BPV_LAUNCH(2, 8);
     else if (tp == 4)

@@ -216,7 +216,8 @@ __device__ __forceinline__ void store_digits(const fq& kk, int c, int W, tdig_t*
 // (8 lanes per multiplication spent 138M VALU instructions per 16384 proofs, mostly in the tree).
 #define FM_SUB 2
 __global__ __launch_bounds__(256) void k_bpv_fixmul(int k, int nm, size_t nproofs, const affine_mem* __restrict__ table, int c, int W,
-                                                    const fq* __restrict__ chal, xyzz* __restrict__ fixres, const int* __restrict__ bad, int nmul) {
+                                                    const fq* __restrict__ chal, xyzz* __restrict__ fixres, const int* __restrict__ bad, int nmul,
+                                                    int ibase) {
     __shared__ xyzz red[256];
     const int tid = threadIdx.x, lane = tid % (2 * FM_SUB), sub = lane % FM_SUB, which = lane / FM_SUB;
     const size_t pr = (size_t)blockIdx.x * (256 / (2 * FM_SUB)) + tid / (2 * FM_SUB);
@@ -224,7 +225,9 @@ __global__ __launch_bounds__(256) void k_bpv_fixmul(int k, int nm, size_t nproof
     xyzz acc = xyzz_inf();
     if (pr < nproofs && !bad[pr] && which < nmul) {
         fq s = chal[pr * CH_COUNT(k) + (which ? CH_XU : CH_Y)];
-        const size_t pG = (size_t)2 * nm;
+        // y multiplies the secp256k1 generator (Point::generator(), range_proof.rs:570-571; table row ibase), x_u the
+        // caller's G (:588; row 2nm) - the same row whenever G is the generator
+        const size_t pG = which ? (size_t)2 * nm : (size_t)ibase;
         uint32_t carry = 0;
         for (int w = 0; w < W; w++) {
             int d = window_digit(s, c, w, carry);
@@ -505,11 +508,11 @@ size_t bpv_cst_count(int k, int m) { return ((size_t)CS_COUNT(k, m) * sizeof(fqm
 
 hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
                                       const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fqm* scF, fq* varS, fq* chal,
-                                      fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st) {
+                                      fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st, int ibase) {
     const int nm = n_bits * m;
     hipLaunchKernelGGL(k_bpv_hash1, dim3((unsigned)((nproofs * 4 + 63) / 64)), dim3(64), 0, st, proofs, proof_len, k, m, nm, nproofs, pts, gens,
                        chal, bad);
-    hipLaunchKernelGGL(k_bpv_fixmul, dim3((unsigned)((nproofs + 256 / (2 * FM_SUB) - 1) / (256 / (2 * FM_SUB)))), dim3(256), 0, st, k, nm, nproofs, table, c, W, chal, fixres, bad, 2);
+    hipLaunchKernelGGL(k_bpv_fixmul, dim3((unsigned)((nproofs + 256 / (2 * FM_SUB) - 1) / (256 / (2 * FM_SUB)))), dim3(256), 0, st, k, nm, nproofs, table, c, W, chal, fixres, bad, 2, ibase);
     hipLaunchKernelGGL(k_bpv_fixinv, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, nproofs, fixres, fixaff, bad);
     hipLaunchKernelGGL(k_bpv_hash2, dim3((unsigned)((nproofs * (k + 1) + 63) / 64)), dim3(64), 0, st, k, m, nproofs, pts, fixaff, chal, bad);
     hipLaunchKernelGGL(k_bpv_consts, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W,
@@ -699,12 +702,12 @@ __global__ __launch_bounds__(64) void k_wipv_consts(const uint8_t* __restrict__ 
 
 hipError_t launch_wipv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
                                        const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fqm* scF, fq* varS, fq* chal,
-                                       fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st) {
+                                       fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st, int ibase) {
     const int nm = n_bits * m;
     hipLaunchKernelGGL(k_wipv_hash1, dim3((unsigned)((nproofs * (k + 2) + 63) / 64)), dim3(64), 0, st, proofs, proof_len, k, m, nm, nproofs, pts,
                        gens, chal, bad);
     hipLaunchKernelGGL(k_bpv_fixmul, dim3((unsigned)((nproofs + 256 / (2 * FM_SUB) - 1) / (256 / (2 * FM_SUB)))), dim3(256), 0, st, k, nm, nproofs,
-                       table, c, W, chal, fixres, bad, 1);
+                       table, c, W, chal, fixres, bad, 1, ibase);
     hipLaunchKernelGGL(k_wipv_fixinv, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, nproofs, fixres, fixaff, bad);
     hipLaunchKernelGGL(k_wipv_hash2, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, k, m, nproofs, pts, fixaff, chal, bad);
     hipLaunchKernelGGL(k_wipv_consts, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W,

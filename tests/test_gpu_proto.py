@@ -248,3 +248,53 @@ def test_prove_batch_reports_bad_inputs(ctx):
             ctx.set_proto_path(0)
     finally:
         gens.close()
+
+
+@pytest.mark.parametrize("kind", (0, 1))
+def test_caller_G_different_from_the_curve_generator(ctx, oracle_c, kind):
+    """y*G of the z challenge multiplies Point::generator() (range_proof.rs:125-126, 570-571; range_proof_wip.rs:169,
+    422), everything else the caller's G: with G != generator the proof bytes and every verifier's verdict still match
+    the oracle (bp_gens keeps an extra table row for the generator in that case)."""
+    from oracle import curv, encoding, tape
+    from oracle.range_proof import RangeProof
+    from oracle.range_proof_wip import RangeProofWIP, StatementRP
+    n, m = 8, 2
+    g_vec, h_vec, _, H = (curv.bpplus_generators if kind else curv.bp_generators)(n, m)
+    G = oracle_c.mul(ec.G, 0xC0FFEE1234567)
+    tb = tape.make_tape_bytes("ownG-%d" % kind, m + (tape.bpplus_tape_len if kind else tape.bp_tape_len)(n, m))
+    v = [200, 17]
+    r = [int.from_bytes(tb[32 * j:32 * j + 32], "big") for j in range(m)]
+    com = [oracle_c.add(oracle_c.mul(G, v[j]), oracle_c.mul(H, r[j])) for j in range(m)]
+    if kind:
+        stmt = StatementRP(g_vec, h_vec, G, H, n)
+        want = RangeProofWIP.prove(stmt, v, r, tape.Tape(tb[32 * m:]))
+        assert want.aggregated_verify(stmt, com) == "Ok"
+        want_b = encoding.encode_bpplus(want)
+    else:
+        want = RangeProof.prove(g_vec, h_vec, G, H, v, r, n, tape.Tape(tb[32 * m:]))
+        assert want.aggregated_verify(g_vec, h_vec, G, H, com, n) == "Ok"
+        want_b = encoding.encode_bp(want)
+    enc = lambda ps: b"".join(ec.enc64(p) for p in ps)
+    gens = bpa.Gens(ctx, enc(g_vec), enc(h_vec), ec.enc64(G), ec.enc64(H), 5)
+    try:
+        prove = ctx.wip_rangeproof_prove if kind else ctx.rangeproof_prove
+        got = prove(gens, n, b"".join(x.to_bytes(32, "big") for x in v), tb[:32 * m], tb[32 * m:])
+        assert got == want_b
+        coms = enc(com)
+        bad = bytearray(got)
+        bad[-1] ^= 1
+        single = ctx.wip_rangeproof_verify if kind else ctx.rangeproof_verify
+        for mode in ((0, 2) if kind else (0, 1, 2)):
+            assert single(gens, n, m, got, coms, mode) == 0, mode
+            assert single(gens, n, m, bytes(bad), coms, mode) != 0, mode
+        batch = ctx.wip_rangeproof_verify_batch if kind else ctx.rangeproof_verify_batch
+        assert batch(gens, n, m, got + bytes(bad) + got, coms * 3) == [0, 3, 0]
+        rlc = ctx.wip_rangeproof_verify_batch_rlc if kind else ctx.rangeproof_verify_batch_rlc
+        assert rlc(gens, n, m, got * 3, coms * 3, bytes(range(32))) == ([0, 0, 0], False)
+        ctx.set_proto_path(1)
+        try:
+            assert prove(gens, n, b"".join(x.to_bytes(32, "big") for x in v), tb[:32 * m], tb[32 * m:]) == want_b
+        finally:
+            ctx.set_proto_path(0)
+    finally:
+        gens.close()
