@@ -10,6 +10,8 @@ from ._lib import (  # noqa: F401
     Gens,
     generate_bases,
     msm_auto_window,
+    noalloc_scratch_bytes,
+    BP_EINVAL,
     KZEN_SEED,
     lib,
     lib_path,

@@ -38,6 +38,8 @@ EXPORTED_SYMBOLS = [
     "bp_wip_rangeproof_verify_batch_rlc_device",
     "bp_rangeproof_verify_batch_rlc_device",
     "bp_ctx_sync",
+    "bp_rangeproof_verify_batch_device_noalloc",
+    "bp_noalloc_scratch_bytes",
     "bp_verify_set_lanes",
     "bp_scalar_mul_batch",
     "bp_fold_bases",
@@ -121,6 +123,10 @@ def lib():
     L.bp_rangeproof_verify_batch_rlc.restype = i32
     L.bp_rangeproof_verify_batch_rlc_device.argtypes = [vp, vp, i32, i32, vp, sz, vp, sz, cp, vp, ctypes.POINTER(i32)]
     L.bp_rangeproof_verify_batch_rlc_device.restype = i32
+    L.bp_rangeproof_verify_batch_device_noalloc.argtypes = [vp, vp, i32, i32, vp, sz, vp, sz, vp]
+    L.bp_rangeproof_verify_batch_device_noalloc.restype = i32
+    L.bp_noalloc_scratch_bytes.argtypes = []
+    L.bp_noalloc_scratch_bytes.restype = sz
     L.bp_ctx_sync.argtypes = [vp]
     L.bp_ctx_sync.restype = i32
     L.bp_verify_set_lanes.argtypes = [vp, i32]
@@ -441,6 +447,15 @@ class Context:
         """Asynchronous device-pointer variant (ints); call sync() before reading verdicts."""
         _check(lib().bp_rangeproof_verify_batch_device(self._h, gens._h, n_bits, m, ctypes.c_void_p(d_proofs), proof_len,
                                                        ctypes.c_void_p(d_coms), nproofs, ctypes.c_void_p(d_verdicts)))
+
+    def rangeproof_verify_batch_device_noalloc(self, gens, n_bits, m, d_proofs, proof_len, d_coms, nproofs, d_verdicts):
+        """rangeproof_verify_batch_device with its workspaces in the library's fixed device array (no hipMalloc)."""
+        _check(lib().bp_rangeproof_verify_batch_device_noalloc(self._h, gens._h, n_bits, m, ctypes.c_void_p(d_proofs), proof_len,
+                                                               ctypes.c_void_p(d_coms), nproofs, ctypes.c_void_p(d_verdicts)))
+
+
+def noalloc_scratch_bytes():
+    return lib().bp_noalloc_scratch_bytes()
 
 
 def msm_auto_window(n):

@@ -337,6 +337,7 @@ int bp_ctx_create(int device, bp_ctx** out) {
         return BP_EINVAL;
     }
     HIPCHK(hipSetDevice(device), "hipSetDevice");
+    if (int rc = noalloc_init_device(device)) return rc;
     bp_ctx* ctx = new bp_ctx();
     ctx->device = device;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);

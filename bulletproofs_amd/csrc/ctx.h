@@ -103,4 +103,5 @@ struct bp_gens {
 namespace bp {
 int msm_fetch_result(bp_ctx* ctx, uint8_t out_xy[64]);
 int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scalars_be, size_t n, const affine_mem* d_init);
+int noalloc_init_device(int device);  // verify_api.cpp: resolves this device's copy of the no-allocation scratch array
 }

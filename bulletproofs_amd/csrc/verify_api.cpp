@@ -1,5 +1,6 @@
 // C ABI: generator tables (bp_gens) and the batched range-proof verifier.  Host plumbing only.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <mutex>
@@ -21,6 +22,7 @@ using namespace bp;
     } while (0)
 
 #define BP_MAX_TABLE_WINDOW 20
+#define BP_NOALLOC_SCRATCH_BYTES (64u << 20)  // 64 MiB per GPU, see bp_rangeproof_verify_batch_device_noalloc
 static int pick_table_window(int np) {
     // widest c in [4, 20] whose table (np * W * 2^(c-1) * 64 B) stays <= 64 GiB of the 288 GB HBM and whose build
     // (table + 2.25x as XYZZ scratch, freed afterwards) fits in 80 % of the memory that is free right now.
@@ -358,6 +360,76 @@ static int verify_batch_launch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int
         ctx->prof_n = 3;
     }
     return BP_OK;
+}
+
+// ---- the no-allocation entry point ---------------------------------------------------------------
+// Callers that cannot call hipMalloc (HIP graph capture, tight serving loops, harnesses that forbid it) get the
+// batch verifier with its workspaces in a file-scope device array instead of the context's grow-only buffers.
+// Every GPU the library runs on holds BP_NOALLOC_SCRATCH_BYTES of it until the process ends.  The array's name is
+// only a host-side stand-in: the per-device address comes from hipGetSymbolAddress (noalloc_init_device, called by
+// bp_ctx_create with the device current) and only that pointer is ever handed to kernels / memsets.
+static __device__ __align__(256) unsigned char scratch[BP_NOALLOC_SCRATCH_BYTES];
+static const int kMaxDevices = 64;
+static unsigned char* g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_mu;
+
+}  // extern "C"
+namespace bp {
+int noalloc_init_device(int device) {  // the device must be current
+    if (device < 0 || device >= kMaxDevices) return BP_OK;  // such a device simply has no no-allocation entry point
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_ptr[device]) return BP_OK;
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) {
+        set_error("hipGetSymbolAddress(scratch)", e);
+        return BP_EHIP;
+    }
+    g_scratch_ptr[device] = (unsigned char*)p;
+    return BP_OK;
+}
+}  // namespace bp
+extern "C" {
+
+size_t bp_noalloc_scratch_bytes(void) { return BP_NOALLOC_SCRATCH_BYTES; }
+
+int bp_rangeproof_verify_batch_device_noalloc(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
+                                              const void* d_coms_xy, size_t nproofs, void* d_verdicts) {
+    int k = 0;
+    int rc = check_batch_args(ctx, gens, n_bits, m, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, &k);
+    if (rc != BP_OK || nproofs == 0) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    unsigned char* base = ctx->device < kMaxDevices ? g_scratch_ptr[ctx->device] : nullptr;
+    if (!base) {
+        set_error_msg("no-allocation entry point: this device's scratch address was not resolved at bp_ctx_create");
+        return BP_EHIP;
+    }
+    const VerifySizes z = verify_ws_sizes(ctx, gens, n_bits, m, k, nproofs, 0);
+    if (nproofs > ((size_t)1 << 24) || z.total() > (size_t)BP_NOALLOC_SCRATCH_BYTES) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "no-allocation entry point: the batch needs %zu bytes of workspace, the fixed scratch holds %zu; split the batch",
+                 z.total(), (size_t)BP_NOALLOC_SCRATCH_BYTES);
+        set_error_msg(msg);
+        return BP_EINVAL;
+    }
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        unsigned char* p = base + off;
+        off += (bytes + 255) / 256 * 256;
+        return p;
+    };
+    VerifyWs ws;
+    ws.pts = (affine_mem*)carve(z.pts);
+    ws.bad = (int*)carve(z.bad);
+    ws.dig = (tdig_t*)carve(z.dig);
+    ws.var = (fq*)carve(z.var);
+    ws.chal = (fq*)carve(z.chal);
+    ws.fixres = (xyzz*)carve(z.fixres);
+    ws.vartab = (xyzz*)carve(z.vartab);
+    // The array keeps the previous call's contents.  Only `bad` must start at zero (verify_batch_launch clears it on the
+    // stream); every other slice is written by the kernels of this call before it is read.
+    return verify_batch_launch(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, 0, ws, z.tp);
 }
 
 int bp_wip_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,

@@ -143,6 +143,19 @@ int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bi
                                       const void* d_coms_xy, size_t nproofs, void* d_verdicts);
 int bp_ctx_sync(bp_ctx* ctx);
 
+/* bp_rangeproof_verify_batch_device_noalloc — bp_rangeproof_verify_batch_device for callers that cannot allocate.
+ * No counterpart in the reference: it exists for callers that may not call hipMalloc (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid allocation).  Same arguments, same kernels, same verdict bytes; the
+ * workspaces (decompressed points, digits, challenge scalars, lane-private window tables) live in a fixed device array
+ * of bp_noalloc_scratch_bytes() = 64 MiB that every GPU the library runs on holds until the process ends, so the call
+ * performs no hipMalloc / hipFree.  A batch whose workspaces exceed it (about 1800 n=64 m=1 proofs with the default
+ * 20-bit table) returns BP_EINVAL and bp_last_error() says how many bytes it needs: split the batch.  All calls on one
+ * GPU share that array: calls that overlap on the same GPU (two contexts, two threads) race — serialise them.
+ * Asynchronous on the context's stream until bp_ctx_sync, like the entry point it mirrors. */
+int bp_rangeproof_verify_batch_device_noalloc(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
+                                              const void* d_coms_xy, size_t nproofs, void* d_verdicts);
+size_t bp_noalloc_scratch_bytes(void);
+
 /* bp_rangeproof_verify_batch_rlc(_device) — the same verdicts as bp_rangeproof_verify_batch, through ONE
  * random-linear-combination check for the whole batch (no counterpart in the reference,
  * which verifies one proof per call): with per-proof 128-bit weights rho_j derived from `seed`,

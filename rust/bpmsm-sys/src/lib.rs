@@ -100,6 +100,11 @@ extern "C" {
     pub fn bp_rangeproof_verify_batch_device(ctx: *mut bp_ctx, gens: *const bp_gens, n_bits: c_int, m: c_int, d_proofs: *const c_void,
                                              proof_len: usize, d_coms_xy: *const c_void, nproofs: usize,
                                              d_verdicts: *mut c_void) -> c_int;
+    // no counterpart in the reference: the same call for callers that cannot allocate (fixed 64 MiB device scratch per GPU)
+    pub fn bp_rangeproof_verify_batch_device_noalloc(ctx: *mut bp_ctx, gens: *const bp_gens, n_bits: c_int, m: c_int,
+                                                     d_proofs: *const c_void, proof_len: usize, d_coms_xy: *const c_void, nproofs: usize,
+                                                     d_verdicts: *mut c_void) -> c_int;
+    pub fn bp_noalloc_scratch_bytes() -> usize;
     pub fn bp_rangeproof_verify_batch_rlc(ctx: *mut bp_ctx, gens: *const bp_gens, n_bits: c_int, m: c_int, proofs: *const u8,
                                           proof_len: usize, coms_xy: *const u8, nproofs: usize, seed: *const u8, verdicts: *mut u8,
                                           used_fallback: *mut c_int) -> c_int;
