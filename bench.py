@@ -11,9 +11,15 @@ Contract (one JSON line on rank 0): metric/value/unit/n_gpus/steps/warmup/ms_per
   "roofline"     — dominant kernel (k_bpv_msm) against the measured VALU INT32-MAD peak,
   "cpu_baseline" — the oracle's aggregated_verify ("port") timed on this host, rank 0, N=1 only.
 
-Synthetic data: 256 distinct proofs from tests/golden/bp_c3_batch_n64_m1.json (made by the oracle
-with seeded tapes; the reference cannot run here), tiled to the batch size; every 16th proof of
-the batch is tampered (tx bit flipped) so both verdicts are exercised and checked.
+Synthetic data: every proof of the batch is DISTINCT (the reference's benches prove fresh proofs,
+benches/range_proof.rs:36-103): made at start-up on the GPU by bp_rangeproof_prove_batch (pinned to the
+oracle's bytes by tests/test_gpu_proto.py) from SHAKE-256-derived secrets / blindings / tapes; every
+16th proof of the batch is tampered (tx bit flipped) so both verdicts are exercised and checked.  A
+batch of identical gather patterns would keep the 52.8 GiB generator table's gathers inside the caches;
+`tiled_256` in the JSON is that easier case, measured once for the record.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself
+(python -m torch.distributed.run ... bench.py --gpus N ...), before anything touches a GPU.
 """
 import argparse
 import json
@@ -32,6 +38,11 @@ MAD32_PER_PROOF_TOTAL = 6.60e6      # + the two fixed-base multiplications y*G, 
 # v_mad_u64_u32 sustains 31.2e12 lane-results/s at 8 waves/SIMD (SURVEY's assumed quarter-rate
 # figure was 9.83e12; the measured one is the denominator used here).
 PEAK_MAD32_PER_S = 31.2e12
+MAD32_PER_POINT_MSM = 11833.0       # SURVEY.md 8(d), C5 model (2^20 points, c = 16)
+# Executed v_mad_u64_u32 lane-results per unit, counted by the instrumented build (scripts/opcount.py ->
+# profiles/r02_opcount.json): field multiplications x 91 + squarings x 55 (static counts of fp_mul / fp_sqr, fp.h).
+EXEC_MAD32_PER_PROOF_MSM = 2.40e6   # k_bpv_msm, n=64 m=1, 20-bit table, 2 lanes per proof  (placeholder until measured)
+EXEC_MAD32_PER_POINT_MSM = None     # whole bp_msm_device pipeline at 2^20 points
 # HBM-side traffic of one k_bpv_msm launch at the default configuration (65536 proofs, auto lanes, 20-bit table
 # windows), from the separate --pmc passes in profiles/r01_pmc_read.csv / r01_pmc_write.csv:
 # TCC_EA0_RDREQ 143.80e6 x 64 B (64-byte gathers of table entries and lane-private window tables, not the
@@ -45,6 +56,7 @@ PMC_TRAFFIC_BYTES_DEFAULT = 143.80e6 * 64 + 36.73e6 * 64 + 19.70e6 * 32
 # Rehearsal of the multi-rank path on a ONE-GPU box (BENCH_REHEARSAL=1 under torch.distributed.run): every rank uses
 # GPU 0 and the collectives go over gloo with host tensors.  Never used by the driver's runs (one rank per GPU, RCCL).
 REHEARSAL = os.environ.get("BENCH_REHEARSAL") == "1"
+REHEARSAL_DRY = os.environ.get("BENCH_REHEARSAL") == "dry"
 
 
 def dist_setup(world, local_rank):
@@ -86,6 +98,9 @@ def parse():
     ap.add_argument("--no-rlc", action="store_true", help="skip the random-linear-combination side measurement")
     ap.add_argument("--no-bpplus", action="store_true", help="skip the Bulletproofs+ batch side measurement")
     ap.add_argument("--no-c2", action="store_true", help="skip the n=64 m=16 batch side measurement")
+    ap.add_argument("--no-msm", action="store_true", help="skip the raw 2^k-point MSM side measurement")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep")
+    ap.add_argument("--no-tiled", action="store_true", help="skip the tiled-batch (round 1 data shape) side measurement")
     ap.add_argument("--prove-threads", type=int, default=8, help="--workload prove: contexts in flight for the throughput figure")
     ap.add_argument("--skip-check", action="store_true", help="timing experiments only: do not compare verdicts")
     ap.add_argument("--cpu-sample", type=int, default=1200, help="proofs verified by the CPU baseline")
@@ -218,7 +233,7 @@ def bench_msm(args):
         ctx_b.close()
     if rank == 0:
         mpts = N * args.steps / dt / 1e6
-        mad_per_point = 11833.0  # SURVEY.md §8(d), C5 model (c = 16)
+        mad_per_point = MAD32_PER_POINT_MSM
         print(json.dumps({
             "metric": "MSM Mpts/s (raw Pippenger MSM, secp256k1)", "value": mpts, "unit": "Mpts/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -357,8 +372,142 @@ def cpu_prove_baseline(case):
             "sample": "%d proves + %d verifies of the C1 fixture by the oracle (C engine: %s)" % (reps, reps, ec.have_c())}
 
 
+def shake(tag, nbytes):
+    """Deterministic synthetic bytes (SHAKE-256 of a tag): one call per array instead of one SHA-256 per scalar."""
+    import hashlib
+    return hashlib.shake_256(tag).digest(nbytes)
+
+
+def scalars_in_range(tag, count):
+    """count 32-byte big-endian scalars in [1, 2^255) (all < q): top bit cleared, low bit set."""
+    import numpy as np
+    a = np.frombuffer(shake(tag, 32 * count), dtype=np.uint8).reshape(count, 32).copy()
+    a[:, 0] &= 0x7F
+    a[:, 31] |= 1
+    return a.tobytes()
+
+
+def make_distinct_batch(ctx, gens, G, H, kind, m, count, tag):
+    """count distinct valid n=64 proofs (+ commitments V_j = v_j G + r_j H) made on the GPU by the batch provers.
+    kind 0 = Bulletproofs, 1 = Bulletproofs+.  Returns (proofs bytes, commitments bytes, proof_len)."""
+    import numpy as np
+    nm = 64 * m
+    k = nm.bit_length() - 1
+    ntape = (1 + 2 * k + 4) if kind else (2 + 2 * nm + 2)
+    v8 = np.frombuffer(shake(b"v-" + tag, 8 * count * m), dtype=np.uint8).reshape(count * m, 8)
+    secs = np.zeros((count * m, 32), dtype=np.uint8)
+    secs[:, 24:] = v8
+    secs = secs.tobytes()
+    blinds = scalars_in_range(b"r-" + tag, count * m)
+    prove = ctx.wip_rangeproof_prove_batch if kind else ctx.rangeproof_prove_batch
+    plen = (195 if kind else 292) + 66 * k
+    out = []
+    CH = 8192 if m == 1 else 512
+    for lo in range(0, count, CH):
+        c = min(CH, count - lo)
+        tapes = scalars_in_range(b"t-%d-" % lo + tag, c * ntape)
+        out += prove(gens, 64, m, secs[32 * m * lo:32 * m * (lo + c)], blinds[32 * m * lo:32 * m * (lo + c)], tapes, 32 * ntape)
+    # commitments: v*G (fixed base), r*H, added by a fold with unit scalars
+    one = (1).to_bytes(32, "big")
+    coms = bytearray()
+    CC = 1 << 15
+    for lo in range(0, count * m, CC):
+        c = min(CC, count * m - lo)
+        vG = ctx.scalar_mul_batch(G * c, secs[32 * lo:32 * (lo + c)])
+        rH = ctx.scalar_mul_batch(H * c, blinds[32 * lo:32 * (lo + c)])
+        coms += ctx.fold_bases(vG, rH, one, one)
+    return b"".join(out), bytes(coms), plen
+
+
+def tamper_batch(pb, plen, count, at):
+    """flip one bit of every 16th proof (byte `at`: tx / delta'); returns the expected verdict bytes"""
+    want = bytearray(count)
+    for j in range(5, count, 16):
+        pb[j * plen + at] ^= 1
+        want[j] = 3
+    return want
+
+
+def spawn_ranks(args):
+    """`bench.py --gpus N` started by hand (no WORLD_SIZE): start N ranks as a child torch.distributed.run and pass its
+    exit code on.  This parent has not touched a GPU and never execs."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def dry_run(args):
+    """BENCH_REHEARSAL=dry: the launcher / rendezvous / barrier / max-over-ranks / JSON plumbing with NO library call
+    (a box without a GPU, tests/test_bench_launcher.py); prints "dry_run": true and value 0 - never a measurement."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "verified range proofs/sec (secp256k1, n=64) at 1/2/4/8 GPUs; MSM Mpts/s", "value": 0.0, "unit": "proofs/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3,
+                          "dry_run": True, "config": {"workload": args.workload}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def msm_side(ctx, dev, log2n, steps):
+    """BASELINE.json configs[4] on this one GPU inside the default run: raw 2^k-point MSM, inputs resident in HBM,
+    one call at a time; result cross-checked between two calls.  (--workload msm is the multi-GPU form.)"""
+    import torch
+    N = 1 << log2n
+    pts = bytearray()
+    CH = 1 << 16
+    for s0 in range(0, N, CH):
+        pts += ctx.fixed_base_mul_batch(scalars_in_range(b"bpmsm-c5-r-%d" % s0, CH))
+    scal = shake(b"bpmsm-c5-k", 32 * N)
+    d_pts = torch.frombuffer(pts, dtype=torch.uint8).to(dev)
+    d_sc = torch.frombuffer(bytearray(scal), dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()
+    res = ctx.msm_device(d_pts.data_ptr(), d_sc.data_ptr(), N)
+    ctx.msm_device(d_pts.data_ptr(), d_sc.data_ptr(), N)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r2 = ctx.msm_device(d_pts.data_ptr(), d_sc.data_ptr(), N)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert r2 == res
+    mpts = N / dt / 1e6
+    return {"value": mpts, "unit": "Mpts/s", "log2_points": log2n, "ms_per_msm": dt * 1e3, "result": res.hex(),
+            "what": "bp_msm_device, one call at a time, inputs resident in HBM, 64-byte result returned to the host",
+            "roofline": {"bound": "valu_int32_mad", "kernel": "whole bp_msm_device pipeline (dominant kernel k_srt_acc)",
+                         "achieved": mpts * 1e6 * MAD32_PER_POINT_MSM / 1e12, "peak": PEAK_MAD32_PER_S / 1e12, "unit": "TMAD32/s",
+                         "frac": mpts * 1e6 * MAD32_PER_POINT_MSM / PEAK_MAD32_PER_S, "frac_model": mpts * 1e6 * MAD32_PER_POINT_MSM / PEAK_MAD32_PER_S,
+                         "frac_executed": (mpts * 1e6 * EXEC_MAD32_PER_POINT_MSM / PEAK_MAD32_PER_S) if EXEC_MAD32_PER_POINT_MSM else None,
+                         "traffic": None}}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
+    if REHEARSAL_DRY:
+        return dry_run(args)
     if args.workload == "msm":
         return bench_msm(args)
     if args.workload == "prove":
@@ -374,36 +523,30 @@ def main():
         raise SystemExit("bench.py needs a GPU (libbpmsm has no CPU path)")
     local_rank, dev, cdev = dist_setup(world, local_rank)
 
-    batch = load_batch()
+    golden = load_batch()
     P = args.proofs_per_gpu
-    plen = 292 + 66 * 6
-    cnt = batch["count"]
-    proofs = bytearray(bytes.fromhex(batch["proofs"]))
-    coms = bytes.fromhex(batch["commitments"])
-    # tile the 256 distinct proofs to P, rotating by rank so ranks do not hold identical shards
-    order = [(i + 37 * rank) % cnt for i in range(P)]
-    pb = bytearray(P * plen)
-    cb = bytearray(P * 64)
-    want = bytearray(P)
-    for j, i in enumerate(order):
-        pb[j * plen:(j + 1) * plen] = proofs[i * plen:(i + 1) * plen]
-        cb[j * 64:(j + 1) * 64] = coms[i * 64:(i + 1) * 64]
-        if j % 16 == 5:
-            pb[j * plen + 4 * 33 + 64 + 31] ^= 1
-            want[j] = 3
+    ctx = bpa.Context(local_rank)
+    g_xy, h_xy, G_xy, H_xy = (bytes.fromhex(golden[x]) for x in ("g_vec", "h_vec", "G", "H"))
+    gens = bpa.Gens(ctx, g_xy, h_xy, G_xy, H_xy, args.window_bits)
+    if args.lanes:
+        ctx.set_verify_lanes(args.lanes)
+    TX_AT = 4 * 33 + 64 + 31  # last byte of tx
+
+    t_gen = time.perf_counter()
+    proofs, coms, plen = make_distinct_batch(ctx, gens, G_xy, H_xy, 0, 1, P, b"bpmsm-bench-c3-rank%d" % rank)
+    t_gen = time.perf_counter() - t_gen
+    pb = bytearray(proofs)
+    want = tamper_batch(pb, plen, P, TX_AT)
     d_proofs = torch.frombuffer(pb, dtype=torch.uint8).to(dev)
-    d_coms = torch.frombuffer(cb, dtype=torch.uint8).to(dev)
+    d_coms = torch.frombuffer(bytearray(coms), dtype=torch.uint8).to(dev)
     d_verdicts = torch.full((P,), 77, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
-    ctx = bpa.Context(local_rank)
-    gens = bpa.Gens(ctx, bytes.fromhex(batch["g_vec"]), bytes.fromhex(batch["h_vec"]), bytes.fromhex(batch["G"]),
-                    bytes.fromhex(batch["H"]), args.window_bits)
-    if args.lanes:
-        ctx.set_verify_lanes(args.lanes)
+    def run(count, dp=d_proofs, dc=d_coms):
+        ctx.rangeproof_verify_batch_device(gens, 64, 1, dp.data_ptr(), plen, dc.data_ptr(), count, d_verdicts.data_ptr())
 
     def step():
-        ctx.rangeproof_verify_batch_device(gens, 64, 1, d_proofs.data_ptr(), plen, d_coms.data_ptr(), P, d_verdicts.data_ptr())
+        run(P)
 
     for _ in range(args.warmup):
         step()
@@ -417,6 +560,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
     # timed region: exactly K steps, barrier + synchronize on both sides
     barrier()
     t0 = time.perf_counter()
@@ -424,34 +574,79 @@ def main():
         step()
     ctx.sync()
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
 
     # per-kernel device time of the dominant kernel, HIP events on the library's own stream
     # (separate pass so event recording does not perturb the timed region)
-    ctx.profile_enable(True)
-    ctx.profile_reset()
-    for _ in range(max(3, min(args.steps, 10))):
-        step()
+    def kernel_ms(fn, reps):
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        for _ in range(reps):
+            fn()
+            ctx.sync()
+        out = {}
+        for name, kid in (("bpv_decompress", 0), ("bpv_scalars", 1), ("bpv_msm", 2)):
+            ms, n = ctx.profile_get(kid)
+            out[name] = ms / max(n, 1)
+        ctx.profile_enable(False)
+        return out
+
+    kms = kernel_ms(step, max(3, min(args.steps, 10)))
+
+    # batch-size sweep on prefixes of the same distinct batch (BASELINE.json configs[2] names 4096 proofs over 8 GPUs =
+    # 512 per GPU: the latency-bound regime), verdicts of every prefix checked
+    sweep = []
+    if not args.no_sweep:
+        for count in (512, 4096, 16384, 65536):
+            if count > P:
+                continue
+            d_verdicts.fill_(77)
+            run(count)
+            ctx.sync()
+            if bytes(d_verdicts[:count].cpu().numpy().tobytes()) != bytes(want[:count]) and not args.skip_check:
+                raise SystemExit("sweep: verdict mismatch at %d proofs" % count)
+            reps = max(args.steps, 20 if count <= 4096 else args.steps)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                run(count)
+            ctx.sync()
+            barrier()
+            dts = max_over_ranks(time.perf_counter() - t0)
+            sweep.append({"proofs_per_launch_per_gpu": count, "ms_per_launch": dts / reps * 1e3, "proofs_per_s": world * count * reps / dts})
+
+    # the round-1 data shape, once, for the record: 256 distinct golden proofs tiled to the batch
+    tiled = None
+    if world == 1 and not args.no_tiled:
+        cnt = golden["count"]
+        gp, gc = bytes.fromhex(golden["proofs"]), bytes.fromhex(golden["commitments"])
+        reps_t = (P + cnt - 1) // cnt
+        tb = bytearray((gp * reps_t)[:P * plen])
+        tamper_batch(tb, plen, P, TX_AT)
+        d_tp = torch.frombuffer(tb, dtype=torch.uint8).to(dev)
+        d_tc = torch.frombuffer(bytearray((gc * reps_t)[:P * 64]), dtype=torch.uint8).to(dev)
+        run(P, d_tp, d_tc)
         ctx.sync()
-    kms = {}
-    for name, kid in (("bpv_decompress", 0), ("bpv_scalars", 1), ("bpv_msm", 2)):
-        ms, n = ctx.profile_get(kid)
-        kms[name] = ms / max(n, 1)
-    ctx.profile_enable(False)
+        if bytes(d_verdicts.cpu().numpy().tobytes()) != bytes(want) and not args.skip_check:
+            raise SystemExit("tiled batch: verdict mismatch")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run(P, d_tp, d_tc)
+        ctx.sync()
+        torch.cuda.synchronize()
+        dtt = time.perf_counter() - t0
+        kt = kernel_ms(lambda: run(P, d_tp, d_tc), 3)
+        tiled = {"value": P * args.steps / dtt, "unit": "proofs/s", "ms_per_step": dtt / args.steps * 1e3, "bpv_msm_ms": kt["bpv_msm"],
+                 "what": "the same launch on 256 distinct proofs tiled to the batch (round 1's data): every gather pattern repeats "
+                         "%d times, so the table gathers stay in the caches - an easier memory pattern, not the metric" % (P // cnt)}
+        del d_tp, d_tc
 
     # Random-linear-combination mode on the all-valid version of the same batch (reported beside the headline
     # value, never as it: `value` is N independent aggregated_verify checks, the reference's semantics).
     rlc = None
     if not args.no_rlc:
-        pv = bytearray(pb)
-        for j in range(P):
-            if want[j]:
-                pv[j * plen + 4 * 33 + 64 + 31] ^= 1
-        d_valid = torch.frombuffer(pv, dtype=torch.uint8).to(dev)
+        d_valid = torch.frombuffer(bytearray(proofs), dtype=torch.uint8).to(dev)
         d_v2 = torch.full((P,), 77, dtype=torch.uint8, device=dev)
         seed = bytes((7 * i + rank) & 255 for i in range(32))
         fb = ctx.rangeproof_verify_batch_rlc_device(gens, 64, 1, d_valid.data_ptr(), plen, d_coms.data_ptr(), P, seed, d_v2.data_ptr())
@@ -480,60 +675,30 @@ def main():
         for t in thr:
             t.join()
         barrier()
-        dt_rlc = time.perf_counter() - t0
+        dt_rlc = max_over_ranks(time.perf_counter() - t0)
         assert not bool(d_v2.any().item()) and not bool(d_v3.any().item())
         ctx_b.close()
         ctx.set_msm_pipeline(0)
-        if world > 1:
-            t = torch.tensor([dt_rlc], dtype=torch.float64, device=cdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_rlc = float(t.item())
         rlc = {"value": world * P * args.steps / dt_rlc, "unit": "proofs/s", "ms_per_step": dt_rlc / args.steps * 1e3, "contexts_in_flight": nthr,
                "what": "bp_rangeproof_verify_batch_rlc_device on the same batch with no tampered proof: one fixed-base MSM over the "
                        "generators + one %d-point Pippenger MSM per step; a failing batch falls back to the per-proof path" % (17 * P)}
+        del d_valid
 
-    # Side measurements on one GPU (reported beside `value`, never as it), proofs made here by the GPU provers
-    # (bp_rangeproof_prove / bp_wip_rangeproof_prove, pinned to the oracle's bytes by tests/test_gpu_proto.py),
-    # tiled to the batch, 1/16 tampered, verdicts checked:
+    # Side measurements on one GPU (reported beside `value`, never as it), DISTINCT proofs made here by the GPU batch
+    # provers (pinned to the oracle's bytes by tests/test_gpu_proto.py), 1/16 tampered, verdicts checked:
     #   bpplus_batch  RangeProofWIP::aggregated_verify (Bulletproofs+), n=64 m=1, as many proofs per step as the headline
     #   c2_batch      RangeProof::aggregated_verify at BASELINE.json configs[1]'s shape, n=64 m=16 (2089-term MSM per proof)
-    def side_batch(kind, m, P_side, distinct, what):
-        import hashlib
+    def side_batch(kind, m, P_side, what):
         nm = 64 * m
         k = nm.bit_length() - 1
         g2, h2, G2, H2 = ctx.generate_bases(kind, bpa.KZEN_SEED, 64, m)
         gens2 = bpa.Gens(ctx, g2, h2, G2, H2, args.window_bits)
-        plen2 = (195 if kind else 292) + 66 * k
-        tamper_at = (33 * (2 * k + 3) + 64 + 31) if kind else (4 * 33 + 64 + 31)  # delta' / tx, last byte
-        ntape = (1 + 2 * k + 4) if kind else (2 + 2 * nm + 2)
-        tag = b"plus" if kind else b"bp"
-
-        def sc(t, i, j):
-            d = bytearray(hashlib.sha256(b"bpmsm-bench-%s-%s-%d-%d-%d" % (tag, t, m, i, j)).digest())
-            d[0] &= 0x7F
-            d[31] |= 1
-            return bytes(d)
-
-        prove = ctx.wip_rangeproof_prove if kind else ctx.rangeproof_prove
-        pfs, cms = [], []
-        for i in range(distinct):
-            vs = [hashlib.sha256(b"bpmsm-bench-v-%d-%d" % (i, j)).digest()[:8].rjust(32, b"\0") for j in range(m)]
-            rs = [sc(b"r", i, j) for j in range(m)]
-            tape = b"".join(sc(b"t", i, j) for j in range(ntape))
-            cms.append(b"".join(ctx.msm(G2 + H2, vs[j] + rs[j], None) for j in range(m)))
-            pfs.append(prove(gens2, 64, b"".join(vs), b"".join(rs), tape))
-        pb2 = bytearray(P_side * plen2)
-        cb2 = bytearray(P_side * 64 * m)
-        want2 = bytearray(P_side)
-        for j in range(P_side):
-            i = j % distinct
-            pb2[j * plen2:(j + 1) * plen2] = pfs[i]
-            cb2[j * 64 * m:(j + 1) * 64 * m] = cms[i]
-            if j % 16 == 5:
-                pb2[j * plen2 + tamper_at] ^= 1
-                want2[j] = 3
+        pf2, cm2, plen2 = make_distinct_batch(ctx, gens2, G2, H2, kind, m, P_side, b"bpmsm-bench-side-%d-%d" % (kind, m))
+        tamper_at = (33 * (2 * k + 3) + 64 + 31) if kind else TX_AT  # delta' / tx, last byte
+        pb2 = bytearray(pf2)
+        want2 = tamper_batch(pb2, plen2, P_side, tamper_at)
         d_p2 = torch.frombuffer(pb2, dtype=torch.uint8).to(dev)
-        d_c2 = torch.frombuffer(cb2, dtype=torch.uint8).to(dev)
+        d_c2 = torch.frombuffer(bytearray(cm2), dtype=torch.uint8).to(dev)
         d_v4 = torch.full((P_side,), 77, dtype=torch.uint8, device=dev)
         fn = ctx.wip_rangeproof_verify_batch_device if kind else ctx.rangeproof_verify_batch_device
 
@@ -554,10 +719,7 @@ def main():
         dt2 = time.perf_counter() - t0
         rlc2 = None
         if kind:  # the same batch without the tampered proofs through the random-linear-combination check, one context
-            for j in range(P_side):
-                if want2[j]:
-                    pb2[j * plen2 + tamper_at] ^= 1
-            d_pv = torch.frombuffer(pb2, dtype=torch.uint8).to(dev)
+            d_pv = torch.frombuffer(bytearray(pf2), dtype=torch.uint8).to(dev)
             seed2 = bytes((11 * i + 3) & 255 for i in range(32))
             fbk = ctx.wip_rangeproof_verify_batch_rlc_device(gens2, 64, m, d_pv.data_ptr(), plen2, d_c2.data_ptr(), P_side, seed2, d_v4.data_ptr())
             assert not fbk and not bool(d_v4.any().item()), "BP+ rlc: all-valid batch must pass the combined check"
@@ -571,25 +733,29 @@ def main():
                     "what": "bp_wip_rangeproof_verify_batch_rlc_device on the all-valid version of the batch"}
         nterms = 2 * nm + 2 * k + m + 5 if not kind else 2 * nm + 2 * k + m + 4
         res = {"value": P_side * args.steps / dt2, "unit": "proofs/s", "ms_per_step": dt2 / args.steps * 1e3, "proofs_per_step": P_side,
-               "msm_terms_per_proof": nterms, "msm_mpts_per_s": P_side * args.steps / dt2 * nterms / 1e6, "table_bytes": gens2.table_bytes,
-               "what": what + " (%d distinct GPU-made proofs tiled, 1/16 tampered, verdicts checked)" % distinct}
+               "msm_terms_per_proof": nterms, "verifier_terms_per_s": P_side * args.steps / dt2 * nterms, "table_bytes": gens2.table_bytes,
+               "what": what + " (%d distinct GPU-made proofs, 1/16 tampered, verdicts checked)" % P_side}
         if rlc2:
             res["rlc"] = rlc2
         gens2.close()
         return res
 
-    plus = c2 = None
+    plus = c2 = msm = None
     if world == 1 and not args.no_bpplus:
-        plus = side_batch(1, 1, P, 64, "bp_wip_rangeproof_verify_batch_device: RangeProofWIP::aggregated_verify (Bulletproofs+), n=64 m=1")
+        plus = side_batch(1, 1, P, "bp_wip_rangeproof_verify_batch_device: RangeProofWIP::aggregated_verify (Bulletproofs+), n=64 m=1")
     if world == 1 and not args.no_c2:
-        c2 = side_batch(0, 16, max(256, P // 16), 16, "bp_rangeproof_verify_batch_device at BASELINE.json configs[1]'s shape: "
+        c2 = side_batch(0, 16, max(256, P // 16), "bp_rangeproof_verify_batch_device at BASELINE.json configs[1]'s shape: "
                         "RangeProof::aggregated_verify, n=64 m=16")
+    if world == 1 and not args.no_msm:
+        msm = msm_side(ctx, dev, args.msm_log2, max(args.steps, 10))
 
     if rank == 0:
         total_proofs = world * P * args.steps
         value = total_proofs / dt
         msm_ms = kms["bpv_msm"]
-        achieved = MAD32_PER_PROOF_MSM * P / (msm_ms * 1e-3) if msm_ms > 0 else 0.0
+        model = MAD32_PER_PROOF_MSM * P / (msm_ms * 1e-3) if msm_ms > 0 else 0.0
+        executed = EXEC_MAD32_PER_PROOF_MSM * P / (msm_ms * 1e-3) if msm_ms > 0 else 0.0
+        by_count = {r["proofs_per_launch_per_gpu"]: r for r in sweep}
         out = {
             "metric": "verified range proofs/sec (secp256k1, n=64) at 1/2/4/8 GPUs; MSM Mpts/s",
             "value": value,
@@ -602,32 +768,46 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32 (256-bit modular integer arithmetic, 9x29-bit limbs on v_mad_u64_u32)",
-            "data": "synthetic (256 distinct oracle-made proofs tiled to the batch, 1/16 tampered)",
-            "config": {"workload": "batch aggregated_verify of independent n=64 m=1 Bulletproofs range proofs "
-                                   "(BASELINE.json configs[2]), %d proofs per GPU per step, proofs sharded, no collective" % P,
+            "data": "synthetic: %d distinct GPU-made proofs per GPU (SHAKE-256 secrets / blindings / tapes), 1/16 tampered, verdicts checked" % P,
+            "config": {"workload": "batch aggregated_verify of %d distinct independent n=64 m=1 Bulletproofs range proofs per GPU per step "
+                                   "(BASELINE.json configs[2]), proofs sharded, no collective" % P,
                        "proofs_per_gpu": P, "msm_terms_per_proof": 147, "table_bytes": gens.table_bytes,
-                       "msm_mpts_per_s": value * 147 / 1e6},
+                       "verifier_terms_per_s": value * 147, "batch_generation_s": t_gen},
             "kernel_ms": kms,
+            "batch_sweep": sweep,
+            "configs2_literal": {"proofs_per_s_at_512_per_gpu": by_count.get(512, {}).get("proofs_per_s"),
+                                 "proofs_per_s_at_4096_per_gpu": by_count.get(4096, {}).get("proofs_per_s"),
+                                 "what": "BASELINE.json configs[2] names 4096 proofs over 8 GPUs = 512 per GPU per launch; 4096 per GPU is "
+                                         "the whole batch on one GPU"},
+            "msm_mpts_per_s": msm["value"] if msm else None,
+            "msm": msm,
+            "tiled_256": tiled,
             "rlc_batch": rlc,
             "bpplus_batch": plus,
             "c2_batch": c2,
             "roofline": {
                 "bound": "valu_int32_mad",
                 "kernel": "k_bpv_msm",
-                "achieved": achieved / 1e12,
+                "achieved": executed / 1e12,
                 "peak": PEAK_MAD32_PER_S / 1e12,
                 "unit": "TMAD32/s",
-                "frac": achieved / PEAK_MAD32_PER_S,
+                "frac": executed / PEAK_MAD32_PER_S,
+                "frac_executed": executed / PEAK_MAD32_PER_S,
+                "frac_model": model / PEAK_MAD32_PER_S,
                 "traffic": PMC_TRAFFIC_BYTES_DEFAULT if (P == 65536 and not args.window_bits and not args.lanes) else None,
-                "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_*.csv)",
-                "algorithmic_mad32_per_proof": MAD32_PER_PROOF_MSM,
+                "traffic_unit": "bytes per launch (PMC, profiles/r02_pmc_*.csv)",
+                "executed_mad32_per_proof": EXEC_MAD32_PER_PROOF_MSM,
+                "model_mad32_per_proof": MAD32_PER_PROOF_MSM,
+                "what": "frac = frac_executed: v_mad_u64_u32 lane-results the kernel executes per proof (counted by the instrumented build, "
+                        "profiles/r02_opcount.json: field multiplications x 91 + squarings x 55) x proofs / launch time / measured peak; "
+                        "frac_model: SURVEY 8(d)'s Pippenger model (146 points, c=5), which charges doublings and buckets a table-based "
+                        "verifier does not execute, so it is not a bound for this kernel",
                 "proofs_per_launch": P,
                 "avg_launch_ms": msm_ms,
-                "whole_job_frac": value / world * MAD32_PER_PROOF_TOTAL / PEAK_MAD32_PER_S,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(batch, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(golden, args.cpu_sample)
         print(json.dumps(out), flush=True)
     gens.close()
     ctx.close()
