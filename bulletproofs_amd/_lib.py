@@ -52,6 +52,12 @@ EXPORTED_SYMBOLS = [
     "bp_rangeproof_verify",
     "bp_wip_rangeproof_prove",
     "bp_wip_rangeproof_verify",
+    "bp_rangeproof_verify_batch_mixed",
+    "bp_wip_rangeproof_verify_batch_mixed",
+    "bp_ipa_prove",
+    "bp_ipa_verify",
+    "bp_wipa_prove",
+    "bp_wipa_verify",
     "bp_profile_enable",
     "bp_profile_reset",
     "bp_profile_get",
@@ -166,6 +172,17 @@ def lib():
     L.bp_rangeproof_verify.restype = i32
     L.bp_wip_rangeproof_verify.argtypes = verify_args
     L.bp_wip_rangeproof_verify.restype = i32
+    for f in (L.bp_rangeproof_verify_batch_mixed, L.bp_wip_rangeproof_verify_batch_mixed):
+        f.argtypes = [vp, vp, i32, cp, ctypes.POINTER(sz), cp, ctypes.POINTER(ctypes.c_uint32), sz, cp]
+        f.restype = i32
+    L.bp_ipa_prove.argtypes = [vp, cp, cp, sz, cp, cp, cp, cp, cp, sz, ctypes.POINTER(sz)]
+    L.bp_ipa_prove.restype = i32
+    L.bp_ipa_verify.argtypes = [vp, cp, cp, sz, cp, cp, cp, sz, i32, cp]
+    L.bp_ipa_verify.restype = i32
+    L.bp_wipa_prove.argtypes = [vp, cp, cp, sz, cp, cp, cp, cp, cp, cp, cp, cp, sz, cp, sz, ctypes.POINTER(sz)]
+    L.bp_wipa_prove.restype = i32
+    L.bp_wipa_verify.argtypes = [vp, cp, cp, sz, cp, cp, cp, cp, cp, sz, i32, cp]
+    L.bp_wipa_verify.restype = i32
     L.bp_profile_enable.argtypes = [vp, i32]
     L.bp_profile_enable.restype = None
     L.bp_profile_reset.argtypes = [vp]
@@ -441,6 +458,49 @@ class Context:
         """mode 0 = verify, 2 = aggregated_verify -> verdict code."""
         v = ctypes.create_string_buffer(1)
         _check(lib().bp_wip_rangeproof_verify(self._h, gens._h, n_bits, m, bytes(proof), len(proof), bytes(coms_xy), mode, v))
+        return v.raw[0]
+
+    def rangeproof_verify_batch_mixed(self, gens, n_bits, proofs, ms, coms_xy, wip=False):
+        """One call for proofs with mixed aggregation sizes: proofs = list of proof bytes, ms = their m values,
+        coms_xy = all commitments concatenated in proof order -> list of verdict codes."""
+        n = len(proofs)
+        off = (ctypes.c_size_t * (n + 1))()
+        for i, p in enumerate(proofs):
+            off[i + 1] = off[i] + len(p)
+        marr = (ctypes.c_uint32 * max(n, 1))(*ms)
+        out = ctypes.create_string_buffer(max(n, 1))
+        fn = lib().bp_wip_rangeproof_verify_batch_mixed if wip else lib().bp_rangeproof_verify_batch_mixed
+        _check(fn(self._h, gens._h, n_bits, b"".join(proofs), off, bytes(coms_xy), marr, n, out))
+        return list(out.raw[:n])
+
+    def ipa_prove(self, g_xy, h_xy, ux_xy, a_be, b_be, P_xy=None):
+        """`InnerProductArg::prove` over caller-supplied bases -> L[k] | R[k] | a | b bytes."""
+        n = len(a_be) // 32
+        out = ctypes.create_string_buffer(66 * 32 + 64)
+        ln = ctypes.c_size_t(0)
+        _check(lib().bp_ipa_prove(self._h, bytes(g_xy), bytes(h_xy), n, bytes(ux_xy), P_xy, bytes(a_be), bytes(b_be), out, len(out), ctypes.byref(ln)))
+        return out.raw[:ln.value]
+
+    def ipa_verify(self, g_xy, hi_tag_xy, ux_xy, P_xy, arg, mode=0):
+        """mode 0 = `InnerProductArg::verify` (recursive), 1 = `fast_verify` -> verdict code (0 / 1 / 255)."""
+        v = ctypes.create_string_buffer(1)
+        _check(lib().bp_ipa_verify(self._h, bytes(g_xy), bytes(hi_tag_xy), len(g_xy) // 64, bytes(ux_xy), bytes(P_xy), bytes(arg), len(arg), mode, v))
+        return v.raw[0]
+
+    def wipa_prove(self, g_xy, h_xy, g_pt, h_pt, a_be, b_be, alpha_be, y_be, tape, P_xy=None):
+        """`WeightedInnerProdArg::prove` over caller-supplied bases; tape = (d_L, d_R) per round, r, s, delta, eta."""
+        n = len(a_be) // 32
+        out = ctypes.create_string_buffer(66 * 32 + 162)
+        ln = ctypes.c_size_t(0)
+        _check(lib().bp_wipa_prove(self._h, bytes(g_xy), bytes(h_xy), n, bytes(g_pt), bytes(h_pt), P_xy, bytes(a_be), bytes(b_be), bytes(alpha_be),
+                                   bytes(y_be), bytes(tape), len(tape), out, len(out), ctypes.byref(ln)))
+        return out.raw[:ln.value]
+
+    def wipa_verify(self, g_xy, hi_tag_xy, g_pt, h_pt, P_xy, y_be, arg, mode=0):
+        """mode 0 = `WeightedInnerProdArg::verify` (recursive), 1 = `fast_verify` -> verdict code (0 / 2 / 255)."""
+        v = ctypes.create_string_buffer(1)
+        _check(lib().bp_wipa_verify(self._h, bytes(g_xy), bytes(hi_tag_xy), len(g_xy) // 64, bytes(g_pt), bytes(h_pt), bytes(P_xy), bytes(y_be),
+                                    bytes(arg), len(arg), mode, v))
         return v.raw[0]
 
     def rangeproof_verify_batch_device(self, gens, n_bits, m, d_proofs, proof_len, d_coms, nproofs, d_verdicts):

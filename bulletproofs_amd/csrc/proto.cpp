@@ -1438,6 +1438,280 @@ int bp_wip_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Standalone arguments over CALLER-SUPPLIED bases (no bp_gens): InnerProductArg::{prove, verify, fast_verify}
+// (inner_product.rs:36, 171, 253) and WeightedInnerProdArg::{prove, verify, fast_verify}
+// (weighted_inner_product.rs:47, 270, 386) as the reference's own tests drive them, with arbitrary a, b.
+// Encodings: InnerProductArg = L_1..L_k | R_1..R_k (33 B SEC1) | a_tag b_tag (32 B BE) = 66k + 64 bytes;
+// WeightedInnerProdArg = L[k] | R[k] | a_tag b_tag (33 B) | r' s' delta' (32 B) = 66k + 162 bytes
+// (the tails of the range-proof encodings, oracle/encoding.py).
+}  // extern "C"
+namespace {
+
+// WeightedInnerProdArg::verify (weighted_inner_product.rs:270-377): recursive, folds the bases every round
+int wip_verify(bp_ctx* ctx, const WipArg& w, const affine_mem* G0, const affine_mem* H0, size_t n, const affine_mem* dg, const affine_mem* dh,
+               const Pt& gh, const Pt& hh, Pt P, const Fq& y, bool& ok) {
+    ok = false;
+    RC(ctx->proto[0].reserve(n * sizeof(affine_mem)));
+    RC(ctx->proto[1].reserve(n * sizeof(affine_mem)));
+    RC(ctx->proto[2].reserve(n * sizeof(affine_mem)));
+    RC(ctx->proto[3].reserve(n * sizeof(affine_mem)));
+    affine_mem* Gb[2] = {(affine_mem*)ctx->proto[0].p, (affine_mem*)ctx->proto[1].p};
+    affine_mem* Hb[2] = {(affine_mem*)ctx->proto[2].p, (affine_mem*)ctx->proto[3].p};
+    const affine_mem *G = G0, *H = H0;
+    int flip = 0;
+    const Fq yinv = y.inv();  // :289 (y != 0 checked by the caller: the reference unwraps)
+    size_t j = 0;
+    while (n != 1) {
+        const size_t h = n / 2;
+        if (j >= w.L.size() || j >= w.R.size()) return BP_OK;  // self.L[0] would index out of bounds and panic
+        Fq x = Transcript().point(w.L[j].b).point(w.R[j].b).point(gh.b).point(hh.b).result_scalar();  // :299-301
+        if (x.is_zero()) return BP_OK;
+        Fq xi = x.inv();
+        RC(dfold(ctx, G, G + h, h, xi, x * yinv.pow(h), Gb[flip]));  // G_hat = x^-1 G_L + (x y^-n') G_R   (:310-318)
+        RC(dfold(ctx, H, H + h, h, x, xi, Hb[flip]));                // H_hat = x H_L + x^-1 H_R           (:321-327)
+        G = Gb[flip];
+        H = Hb[flip];
+        flip ^= 1;
+        Pt Pn;
+        RC(dmsm(ctx, {}, {w.L[j], w.R[j], P}, {x * x, xi * xi, Fq(1)}, Pn));  // P_tag   (:330-332)
+        P = Pn;
+        n = h;
+        j++;
+    }
+    Fq e = Transcript().point(w.a_tag.b).point(w.b_tag.b).point(gh.b).point(hh.b).result_scalar();  // :348-350
+    Pt left, right;
+    RC(dmsm(ctx, {}, {P, w.a_tag, w.b_tag}, {e * e, e, Fq(1)}, left));  // e^2 P + e A + B   (:357-359)
+    RC(dmsm(ctx, {Part(G, 1), Part(H, 1), Part(dg, 1), Part(dh, 1)}, {},
+            {e * w.r_prime, e * w.s_prime, w.r_prime * w.s_prime * y, w.delta_prime}, right));  // :362-370
+    ok = left == right;
+    return BP_OK;
+}
+
+// device copy of caller-supplied bases: G[n] | H[n] | two single points, in ctx->proto[4]
+int upload_arg_bases(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t n, const uint8_t* p1, const uint8_t* p2, affine_mem** d) {
+    RC(ctx->proto[4].reserve((2 * n + 2) * sizeof(affine_mem)));
+    *d = (affine_mem*)ctx->proto[4].p;
+    RC(dupload(ctx, g_xy, n, *d));
+    RC(dupload(ctx, h_xy, n, *d + n));
+    RC(dupload(ctx, p1, 1, *d + 2 * n));
+    if (p2) RC(dupload(ctx, p2, 1, *d + 2 * n + 1));
+    return BP_OK;
+}
+bool pt_valid(const uint8_t* xy) { return affine_mem_valid(affine_mem_from_be64(xy), false); }
+std::vector<Fq> scalars_from_be(const uint8_t* be, size_t n) {
+    std::vector<Fq> v(n);
+    for (size_t i = 0; i < n; i++) v[i] = Fq::from_be(be + 32 * i);
+    return v;
+}
+
+}  // namespace
+extern "C" {
+
+int bp_ipa_prove(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t n, const uint8_t ux_xy[64], const uint8_t* P_xy,
+                 const uint8_t* a_be, const uint8_t* b_be, uint8_t* arg_out, size_t arg_cap, size_t* arg_len) {
+    (void)P_xy;  // the reference's prove never reads P (inner_product.rs:36-169)
+    if (!ctx || !g_xy || !h_xy || !ux_xy || !a_be || !b_be || !arg_out || !arg_len || n == 0) return BP_EINVAL;
+    const int k = log2_exact(n);
+    if (k < 0 || k > 24) {  // assert!(n.is_power_of_two())  (:53)
+        set_error_msg("inner-product argument: n must be a power of two");
+        return BP_EINVAL;
+    }
+    const size_t len = 66 * (size_t)k + 64;
+    if (arg_cap < len) return BP_EINVAL;
+    if (!pt_valid(ux_xy)) return BP_EPOINT;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    affine_mem* d;
+    RC(upload_arg_bases(ctx, g_xy, h_xy, n, ux_xy, nullptr, &d));
+    Pt ux;
+    memcpy(ux.b, ux_xy, 64);
+    Ipa out;
+    RC(ipa_prove(ctx, d, d + n, n, ux, scalars_from_be(a_be, n), scalars_from_be(b_be, n), out));
+    uint8_t* q = arg_out;
+    for (int j = 0; j < k; j++, q += 33) host_compress(out.L[j].b, q);
+    for (int j = 0; j < k; j++, q += 33) host_compress(out.R[j].b, q);
+    out.a.to_be(q);
+    out.b.to_be(q + 32);
+    *arg_len = len;
+    return BP_OK;
+}
+
+int bp_ipa_verify(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* hi_tag_xy, size_t n, const uint8_t ux_xy[64], const uint8_t P_xy[64],
+                  const uint8_t* arg, size_t arg_len, int mode, uint8_t* verdict) {
+    if (!ctx || !g_xy || !hi_tag_xy || !ux_xy || !P_xy || !arg || !verdict || n == 0 || (mode != 0 && mode != 1)) return BP_EINVAL;
+    const int k = log2_exact(n);
+    if (k < 0 || k > 24 || arg_len != 66 * (size_t)k + 64) {  // assert!(n.is_power_of_two())  (:185, :267)
+        set_error_msg("inner-product argument: n must be a power of two and arg_len = 66 log2(n) + 64");
+        return BP_EINVAL;
+    }
+    if (!pt_valid(ux_xy)) return BP_EPOINT;
+    if (!host_is_inf(P_xy) && !pt_valid(P_xy)) return BP_EPOINT;
+    Ipa p;
+    p.L.resize(k);
+    p.R.resize(k);
+    const uint8_t* q = arg;
+    bool wellformed = true;
+    for (int j = 0; j < k; j++, q += 33) wellformed = wellformed && host_decompress(q, p.L[j].b);
+    for (int j = 0; j < k; j++, q += 33) wellformed = wellformed && host_decompress(q, p.R[j].b);
+    if (!wellformed || !fq_be_is_canonical(q) || !fq_be_is_canonical(q + 32)) {
+        *verdict = BP_VERDICT_MALFORMED;
+        return BP_OK;
+    }
+    p.a = Fq::from_be(q);
+    p.b = Fq::from_be(q + 32);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    affine_mem* d;
+    RC(upload_arg_bases(ctx, g_xy, hi_tag_xy, n, ux_xy, nullptr, &d));
+    Pt ux, P;
+    memcpy(ux.b, ux_xy, 64);
+    memcpy(P.b, P_xy, 64);
+    bool ok = false;
+    if (mode == 0) {
+        RC(ipa_verify(ctx, p, d, d + n, n, ux, P, ok));  // :171-244
+    } else {
+        // fast_verify (:253-345): one MSM of 2n + 2k + 1 terms compared with P
+        std::vector<Fq> x, xinv;
+        if (ipa_challenges(p, ux, x, xinv) != BP_OK) {  // x.invert().unwrap() on a zero challenge
+            *verdict = BP_VERDICT_MALFORMED;
+            return BP_OK;
+        }
+        std::vector<Fq> s = s_vector(x, xinv, n), sc(2 * n);
+        for (size_t i = 0; i < n; i++) {
+            sc[i] = p.a * s[i];              // a s_i        (:308-311)
+            sc[n + i] = p.b * s[n - 1 - i];  // b s_i^-1     (:312-317)
+        }
+        std::vector<Pt> extras;
+        for (int j = 0; j < k; j++) {
+            extras.push_back(p.L[j]);
+            sc.push_back(-(x[j] * x[j]));
+        }
+        for (int j = 0; j < k; j++) {
+            extras.push_back(p.R[j]);
+            sc.push_back(-(xinv[j] * xinv[j]));
+        }
+        extras.push_back(ux);
+        sc.push_back(p.a * p.b);  // c = a b   (:319-320)
+        Pt lhs;
+        RC(dmsm(ctx, {Part(d, n), Part(d + n, n)}, extras, sc, lhs));
+        ok = lhs == P;  // :340
+    }
+    *verdict = ok ? BP_VERDICT_OK : BP_VERDICT_INNER_PRODUCT_ERROR;
+    return BP_OK;
+}
+
+int bp_wipa_prove(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t n, const uint8_t g_pt[64], const uint8_t h_pt[64],
+                  const uint8_t* P_xy, const uint8_t* a_be, const uint8_t* b_be, const uint8_t alpha_be[32], const uint8_t y_be[32],
+                  const uint8_t* tape, size_t tape_len, uint8_t* arg_out, size_t arg_cap, size_t* arg_len) {
+    (void)P_xy;  // never read by the reference's prove (weighted_inner_product.rs:47-268)
+    if (!ctx || !g_xy || !h_xy || !g_pt || !h_pt || !a_be || !b_be || !alpha_be || !y_be || !tape || !arg_out || !arg_len || n == 0)
+        return BP_EINVAL;
+    const int k = log2_exact(n);
+    if (k < 0 || k > 24) {  // assert!(n.is_power_of_two())  (:67)
+        set_error_msg("weighted inner-product argument: n must be a power of two");
+        return BP_EINVAL;
+    }
+    const size_t len = 66 * (size_t)k + 162;
+    if (arg_cap < len || tape_len < 32 * (size_t)(2 * k + 4)) return BP_EINVAL;
+    if (!pt_valid(g_pt) || !pt_valid(h_pt)) return BP_EPOINT;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    affine_mem* d;
+    RC(upload_arg_bases(ctx, g_xy, h_xy, n, g_pt, h_pt, &d));
+    Pt gh, hh;
+    memcpy(gh.b, g_pt, 64);
+    memcpy(hh.b, h_pt, 64);
+    Tape tp{tape, tape_len};
+    WipArg w;
+    RC(wip_prove(ctx, d, d + n, n, d + 2 * n, d + 2 * n + 1, gh, hh, scalars_from_be(a_be, n), scalars_from_be(b_be, n), Fq::from_be(alpha_be),
+                 Fq::from_be(y_be), tp, w));
+    uint8_t* q = arg_out;
+    for (int j = 0; j < k; j++, q += 33) host_compress(w.L[j].b, q);
+    for (int j = 0; j < k; j++, q += 33) host_compress(w.R[j].b, q);
+    host_compress(w.a_tag.b, q);
+    host_compress(w.b_tag.b, q + 33);
+    q += 66;
+    w.r_prime.to_be(q);
+    w.s_prime.to_be(q + 32);
+    w.delta_prime.to_be(q + 64);
+    *arg_len = len;
+    return BP_OK;
+}
+
+int bp_wipa_verify(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* hi_tag_xy, size_t n, const uint8_t g_pt[64], const uint8_t h_pt[64],
+                   const uint8_t P_xy[64], const uint8_t y_be[32], const uint8_t* arg, size_t arg_len, int mode, uint8_t* verdict) {
+    if (!ctx || !g_xy || !hi_tag_xy || !g_pt || !h_pt || !P_xy || !y_be || !arg || !verdict || n == 0 || (mode != 0 && mode != 1)) return BP_EINVAL;
+    const int k = log2_exact(n);
+    if (k < 0 || k > 24 || arg_len != 66 * (size_t)k + 162) {  // assert!(n.is_power_of_two())  (:286, :402)
+        set_error_msg("weighted inner-product argument: n must be a power of two and arg_len = 66 log2(n) + 162");
+        return BP_EINVAL;
+    }
+    if (!pt_valid(g_pt) || !pt_valid(h_pt)) return BP_EPOINT;
+    if (!host_is_inf(P_xy) && !pt_valid(P_xy)) return BP_EPOINT;
+    WipArg w;
+    w.L.resize(k);
+    w.R.resize(k);
+    const uint8_t* q = arg;
+    bool wellformed = true;
+    for (int j = 0; j < k; j++, q += 33) wellformed = wellformed && host_decompress(q, w.L[j].b);
+    for (int j = 0; j < k; j++, q += 33) wellformed = wellformed && host_decompress(q, w.R[j].b);
+    wellformed = wellformed && host_decompress(q, w.a_tag.b) && host_decompress(q + 33, w.b_tag.b);
+    q += 66;
+    for (int i = 0; i < 3; i++) wellformed = wellformed && fq_be_is_canonical(q + 32 * i);
+    const Fq y = Fq::from_be(y_be);
+    if (!wellformed || y.is_zero()) {  // mod_inv(y).unwrap()  (:289, :405)
+        *verdict = BP_VERDICT_MALFORMED;
+        return BP_OK;
+    }
+    w.r_prime = Fq::from_be(q);
+    w.s_prime = Fq::from_be(q + 32);
+    w.delta_prime = Fq::from_be(q + 64);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    affine_mem* d;
+    RC(upload_arg_bases(ctx, g_xy, hi_tag_xy, n, g_pt, h_pt, &d));
+    Pt gh, hh, P;
+    memcpy(gh.b, g_pt, 64);
+    memcpy(hh.b, h_pt, 64);
+    memcpy(P.b, P_xy, 64);
+    bool ok = false;
+    if (mode == 0) {
+        RC(wip_verify(ctx, w, d, d + n, n, d + 2 * n, d + 2 * n + 1, gh, hh, P, y, ok));
+    } else {
+        // fast_verify (:386-515): delta' h + sum (e r' sg_i) G_i + (e s' sh_i) H_i - e^2 x_j^2 L_j - e^2 x_j^-2 R_j + (r' s' y) g
+        //                         == e^2 P + e A + B
+        WipChal c;
+        if (!wip_challenges(w, gh, hh, n, y, c)) {
+            *verdict = BP_VERDICT_MALFORMED;
+            return BP_OK;
+        }
+        const Fq e = c.e, esq = c.e * c.e;
+        std::vector<Fq> sc(2 * n);
+        for (size_t i = 0; i < n; i++) {
+            sc[i] = w.r_prime * (e * c.sg[i]);      // :471-476
+            sc[n + i] = w.s_prime * (e * c.sh[i]);  // :477-482
+        }
+        sc.push_back(w.r_prime * w.s_prime * y);  // g   (:483-484, :491)
+        sc.push_back(w.delta_prime);              // h   (:500)
+        std::vector<Pt> extras;
+        for (int j = 0; j < k; j++) {
+            extras.push_back(w.L[j]);
+            sc.push_back(-(esq * c.x[j] * c.x[j]));
+        }
+        for (int j = 0; j < k; j++) {
+            extras.push_back(w.R[j]);
+            sc.push_back(-(esq * c.xinv[j] * c.xinv[j]));
+        }
+        Pt lhs, rhs;
+        RC(dmsm(ctx, {Part(d, n), Part(d + n, n), Part(d + 2 * n, 2)}, extras, sc, lhs));
+        RC(dmsm(ctx, {}, {P, w.a_tag, w.b_tag}, {esq, e, Fq(1)}, rhs));  // :506-508
+        ok = lhs == rhs;
+    }
+    *verdict = ok ? BP_VERDICT_OK : BP_VERDICT_WEIGHTED_INNER_PROD_ERROR;
+    return BP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Batch provers: N independent proofs over the same generators.  Every proof runs the single-proof code above on its
 // own host thread; their table-MSM calls are merged into one GPU launch per protocol step (FbBatcher).
 static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, size_t nproofs, const uint8_t* secrets_be,

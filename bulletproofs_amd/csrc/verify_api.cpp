@@ -342,15 +342,15 @@ static int verify_batch_launch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int
     prof_mark(ctx, 1);
     if (wip)
         HIPCHK(launch_wipv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, ws.pts, gens->d_pts, gens->d_table, gens->c,
-                                           gens->W, ws.dig, nullptr, ws.var, d_chal, d_cst, d_fixres, d_fixaff, ws.bad, st, gens->ibase),
+                                           gens->W, ws.dig, nullptr, ws.var, d_chal, d_cst, d_fixres, d_fixaff, ws.bad, st, gens->ibase, (int)gens->nm),
                "wipv_scalars");
     else
         HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, ws.pts, gens->d_pts, gens->d_table, gens->c,
-                                          gens->W, ws.dig, nullptr, ws.var, d_chal, d_cst, d_fixres, d_fixaff, ws.bad, st, gens->ibase),
+                                          gens->W, ws.dig, nullptr, ws.var, d_chal, d_cst, d_fixres, d_fixaff, ws.bad, st, gens->ibase, (int)gens->nm),
                "bpv_scalars");
     prof_mark(ctx, 2);
     HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, ws.pts, gens->d_table, gens->c, gens->W, ws.dig, ws.var, ws.vartab, ws.bad,
-                          (uint8_t*)d_verdicts, st, wip),
+                          (uint8_t*)d_verdicts, st, wip, (int)gens->nm),
            "bpv_msm");
     prof_mark(ctx, 3);
     if (ctx->profiling) {
@@ -502,7 +502,7 @@ static int verify_batch_rlc_device_impl(bp_ctx* ctx, const bp_gens* gens, int n_
                "wipv_decompress");
         HIPCHK(launch_wipv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
                                            gens->d_table, gens->c, W, nullptr, (fqm*)b_scF.p, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
-                                           (int*)b_bad.p, st, gens->ibase),
+                                           (int*)b_bad.p, st, gens->ibase, (int)gens->nm),
                "wipv_scalars");
     } else {
         HIPCHK(launch_bpv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, (affine_mem*)b_pts.p,
@@ -510,7 +510,7 @@ static int verify_batch_rlc_device_impl(bp_ctx* ctx, const bp_gens* gens, int n_
                "bpv_decompress");
         HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, (const affine_mem*)b_pts.p, gens->d_pts,
                                           gens->d_table, gens->c, W, nullptr, (fqm*)b_scF.p, (fq*)b_var.p, d_chal, d_cst, d_fixres, d_fixaff,
-                                          (int*)b_bad.p, st, gens->ibase),
+                                          (int*)b_bad.p, st, gens->ibase, (int)gens->nm),
                "bpv_scalars");
     }
     HIPCHK(launch_rlc_weights(misc + o_seed, nproofs, (const int*)b_bad.p, (fqm*)b_rho.p, st), "rlc_weights");
@@ -701,6 +701,73 @@ int bp_wip_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits,
     HIPCHK(hipStreamSynchronize(ctx->stream), "sync");
     memcpy(verdicts, tmp.data(), nproofs);
     return BP_OK;
+}
+
+
+// Batches mixing aggregation sizes (proof_off[] + m_per_proof[]): proofs are grouped by m on the host, each
+// group is one launch of the batch verifier over the PREFIXES g_vec[..n m_i], h_vec[..n m_i] of the generators (what a
+// caller of the reference passes as slices, range_proof.rs:556-557); verdicts return in the caller's order.
+static int verify_batch_mixed(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint8_t* proofs, const size_t* proof_off, const uint8_t* coms_xy,
+                              const uint32_t* m_per_proof, size_t nproofs, uint8_t* verdicts, int wip) {
+    if (!ctx || !gens || n_bits <= 0 || n_bits > 128 || gens->device != ctx->device) return BP_EINVAL;
+    if (nproofs == 0) return BP_OK;
+    if (!proofs || !proof_off || !coms_xy || !m_per_proof || !verdicts) return BP_EINVAL;
+    struct Group {
+        int m, k;
+        std::vector<size_t> idx;
+    };
+    std::vector<Group> groups;
+    std::vector<size_t> com_off(nproofs + 1, 0);
+    for (size_t i = 0; i < nproofs; i++) {
+        const uint32_t m = m_per_proof[i];
+        const size_t nm = (size_t)n_bits * m;
+        if (m == 0 || nm > gens->nm || (nm & (nm - 1)) != 0) {
+            set_error_msg("mixed batch: every n_bits*m must be a power of two not above the generators' nm (range_proof.rs:556-558)");
+            return BP_EINVAL;
+        }
+        int k = 0;
+        while (((size_t)1 << k) < nm) k++;
+        if (proof_off[i + 1] < proof_off[i] || proof_off[i + 1] - proof_off[i] != (size_t)(wip ? 195 : 292) + 66 * (size_t)k) {
+            set_error_msg("mixed batch: proof length inconsistent with its m");
+            return BP_EINVAL;
+        }
+        com_off[i + 1] = com_off[i] + (size_t)m * 64;
+        size_t g = 0;
+        while (g < groups.size() && groups[g].m != (int)m) g++;
+        if (g == groups.size()) groups.push_back(Group{(int)m, k, {}});
+        groups[g].idx.push_back(i);
+    }
+    std::vector<uint8_t> pb, cb, vb;
+    for (const Group& g : groups) {
+        const size_t cnt = g.idx.size(), plen = (size_t)(wip ? 195 : 292) + 66 * (size_t)g.k, clen = (size_t)g.m * 64;
+        pb.resize(cnt * plen);
+        cb.resize(cnt * clen);
+        vb.resize(cnt);
+        for (size_t j = 0; j < cnt; j++) {
+            memcpy(&pb[j * plen], proofs + proof_off[g.idx[j]], plen);
+            memcpy(&cb[j * clen], coms_xy + com_off[g.idx[j]], clen);
+        }
+        void *d_p, *d_c, *d_v;
+        int rc = stage_batch(ctx, pb.data(), plen, cb.data(), g.m, cnt, &d_p, &d_c, &d_v);
+        if (rc != BP_OK) return rc;
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            rc = verify_batch_device_nolock(ctx, gens, n_bits, g.m, g.k, d_p, plen, d_c, cnt, d_v, wip);
+            if (rc != BP_OK) return rc;
+            HIPCHK(hipMemcpyAsync(vb.data(), d_v, cnt, hipMemcpyDeviceToHost, ctx->stream), "memcpy verdicts");
+            HIPCHK(hipStreamSynchronize(ctx->stream), "sync");
+        }
+        for (size_t j = 0; j < cnt; j++) verdicts[g.idx[j]] = vb[j];
+    }
+    return BP_OK;
+}
+int bp_rangeproof_verify_batch_mixed(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint8_t* proofs, const size_t* proof_off,
+                                     const uint8_t* coms_xy, const uint32_t* m_per_proof, size_t nproofs, uint8_t* verdicts) {
+    return verify_batch_mixed(ctx, gens, n_bits, proofs, proof_off, coms_xy, m_per_proof, nproofs, verdicts, 0);
+}
+int bp_wip_rangeproof_verify_batch_mixed(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint8_t* proofs, const size_t* proof_off,
+                                         const uint8_t* coms_xy, const uint32_t* m_per_proof, size_t nproofs, uint8_t* verdicts) {
+    return verify_batch_mixed(ctx, gens, n_bits, proofs, proof_off, coms_xy, m_per_proof, nproofs, verdicts, 1);
 }
 
 }  // extern "C"

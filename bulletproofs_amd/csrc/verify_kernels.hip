@@ -97,7 +97,7 @@ template <int TP, int PPL>
 __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int m, int k, size_t nproofs, const affine_mem* __restrict__ pts,
                                                  const affine_mem* __restrict__ table, int c, int W, const tdig_t* __restrict__ digF,
                                                  const fq* __restrict__ varS, xyzz* __restrict__ vartab, int8_t* __restrict__ vardig,
-                                                 const int* __restrict__ bad, uint8_t* __restrict__ verdicts, int wip) {
+                                                 const int* __restrict__ bad, uint8_t* __restrict__ verdicts, int wip, int shiftW) {
     __shared__ xyzz red[256];
     const int tid = threadIdx.x;
     const int lane = tid % TP;
@@ -113,10 +113,14 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
     if (active) {
         const int nfw = (2 * nm + 2) * W;
         const tdig_t* dg = digF + pr * (size_t)nfw;
+        // shiftW != 0: the proof uses the first nm of the table's nm_tab generators per vector (a batch mixing aggregation
+        // sizes over one bp_gens): h_vec's rows start (nm_tab - nm) rows later, G and H twice that
+        const int hW = nm * W, gW = 2 * nm * W;
         for (int idx = lane; idx < nfw; idx += TP) {
             int d = dg[idx];
             if (d != 0) {
-                affine e = affine_load(table[(size_t)idx * NB + ((d < 0 ? -d : d) - 1)]);
+                const int row = idx + (idx >= hW ? shiftW : 0) + (idx >= gW ? shiftW : 0);
+                affine e = affine_load(table[(size_t)row * NB + ((d < 0 ? -d : d) - 1)]);
                 if (d < 0) e.y = fp_neg(e.y);
                 xyzz_madd(acc, e);
             }
@@ -187,12 +191,13 @@ size_t bpv_msm_vartab_bytes(int tp, size_t nproofs) {
     return blocks * 256 * bpv_ppl(tp) * (ECMUL_SLOTS * sizeof(xyzz) + ECMUL_DIGB);
 }
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
-                          const tdig_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st, int wip) {
+                          const tdig_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st, int wip, int nm_tab) {
+    const int shiftW = nm_tab > n_bits * m ? (nm_tab - n_bits * m) * W : 0;
     unsigned blocks = (unsigned)((nproofs + (256 / tp) - 1) / (256 / tp));
     int8_t* vardig = reinterpret_cast<int8_t*>(vartab + (size_t)blocks * 256 * bpv_ppl(tp) * ECMUL_SLOTS);
 #define BPV_LAUNCH(TP, PPL)                                                                                                                  \
     hipLaunchKernelGGL((k_bpv_msm<TP, PPL>), dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, vardig, \
-                       bad, verdicts, wip)
+                       bad, verdicts, wip, shiftW)
     if (tp == 2)
         BPV_LAUNCH(2, 8);
     else if (tp == 4)

@@ -143,6 +143,20 @@ int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bi
                                       const void* d_coms_xy, size_t nproofs, void* d_verdicts);
 int bp_ctx_sync(bp_ctx* ctx);
 
+/* bp_rangeproof_verify_batch_mixed / bp_wip_rangeproof_verify_batch_mixed — one call for a block of proofs with MIXED
+ * aggregation sizes (`aggregated_verify` x N, range_proof.rs:537-782 / range_proof_wip.rs:388-609, each proof with its
+ * own m = ped_com.len()).  Proof i is bytes [proof_off[i], proof_off[i+1]) of `proofs` (proof_off has nproofs + 1
+ * entries) and owns the next m_per_proof[i] commitments of coms_xy.  gens holds the generators of the LARGEST size;
+ * a proof with a smaller n_bits*m_i uses the prefixes g_vec[..n m_i], h_vec[..n m_i] — the slices a caller of the
+ * reference passes (:556-557; both generator recipes are prefix-stable: label = seed + i / seed + n + i).  Proofs are
+ * grouped by m internally, one launch per group; verdicts come back in the caller's order, identical to verifying
+ * every proof alone.  BP_EINVAL where the reference asserts: an n_bits*m_i that is not a power of two or exceeds the
+ * gens' nm, a proof length other than 292 (195) + 66 log2(n_bits*m_i). */
+int bp_rangeproof_verify_batch_mixed(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint8_t* proofs, const size_t* proof_off,
+                                     const uint8_t* coms_xy, const uint32_t* m_per_proof, size_t nproofs, uint8_t* verdicts);
+int bp_wip_rangeproof_verify_batch_mixed(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint8_t* proofs, const size_t* proof_off,
+                                         const uint8_t* coms_xy, const uint32_t* m_per_proof, size_t nproofs, uint8_t* verdicts);
+
 /* bp_rangeproof_verify_batch_device_noalloc — bp_rangeproof_verify_batch_device for callers that cannot allocate.
  * No counterpart in the reference: it exists for callers that may not call hipMalloc (code under HIP graph capture,
  * tight serving loops, harnesses that forbid allocation).  Same arguments, same kernels, same verdict bytes; the
@@ -262,6 +276,34 @@ int bp_wip_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const 
  * `aggregated_verify` (mode 2, :388-609). */
 int bp_wip_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proof, size_t proof_len,
                              const uint8_t* coms_xy, int mode, uint8_t* verdict);
+
+/* Standalone arguments over CALLER-SUPPLIED bases (no bp_gens) — the public API of the argument layer as the
+ * reference's own tests drive it, with arbitrary a, b (inner_product.rs:373-690, weighted_inner_product.rs:863-948).
+ * n = g_vec.len() must be a power of two (BP_EINVAL where the reference asserts, inner_product.rs:53, 185, 267;
+ * weighted_inner_product.rs:67, 286, 402).  Zero entries of a / b are legal (the reference skips them, :74).
+ *
+ * bp_ipa_prove — `InnerProductArg::prove(G, H, ux, P, a, b, ..)` (inner_product.rs:36-169).  P_xy is accepted for
+ *   signature parity and never read (the reference's prove does not read it either); may be NULL.
+ *   arg_out: L_1..L_k | R_1..R_k (33 B SEC1 each) | a_tag b_tag (32 B BE) = 66 log2(n) + 64 bytes.
+ * bp_ipa_verify — mode 0: `InnerProductArg::verify` (recursive, folds the bases every round, :171-244);
+ *   mode 1: `fast_verify` (one MSM of 2n + 2 log2(n) + 1 terms, :253-345).  *verdict: BP_VERDICT_OK,
+ *   BP_VERDICT_INNER_PRODUCT_ERROR, or BP_VERDICT_MALFORMED (undeserialisable argument / zero challenge). */
+int bp_ipa_prove(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t n, const uint8_t ux_xy[64], const uint8_t* P_xy,
+                 const uint8_t* a_be, const uint8_t* b_be, uint8_t* arg_out, size_t arg_cap, size_t* arg_len);
+int bp_ipa_verify(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* hi_tag_xy, size_t n, const uint8_t ux_xy[64], const uint8_t P_xy[64],
+                  const uint8_t* arg, size_t arg_len, int mode, uint8_t* verdict);
+/* bp_wipa_prove — `WeightedInnerProdArg::prove(G, H, g, h, P, a, b, alpha, y, ..)` (weighted_inner_product.rs:47-268).
+ *   tape: the `Scalar::random()` draws in the reference's order — (d_L, d_R) per round (:106, :134), then r, s, delta,
+ *   eta (:213-219) — 2 log2(n) + 4 scalars in [1, q).  P_xy never read (as in the reference), may be NULL.
+ *   arg_out: L[k] | R[k] | a_tag b_tag (33 B) | r' s' delta' (32 B) = 66 log2(n) + 162 bytes.
+ * bp_wipa_verify — mode 0: `WeightedInnerProdArg::verify` (recursive, :270-377); mode 1: `fast_verify` (:386-515).
+ *   *verdict: BP_VERDICT_OK, BP_VERDICT_WEIGHTED_INNER_PROD_ERROR or BP_VERDICT_MALFORMED (also y = 0: the reference
+ *   unwraps mod_inv(y), :289). */
+int bp_wipa_prove(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t n, const uint8_t g_pt[64], const uint8_t h_pt[64],
+                  const uint8_t* P_xy, const uint8_t* a_be, const uint8_t* b_be, const uint8_t alpha_be[32], const uint8_t y_be[32],
+                  const uint8_t* tape, size_t tape_len, uint8_t* arg_out, size_t arg_cap, size_t* arg_len);
+int bp_wipa_verify(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* hi_tag_xy, size_t n, const uint8_t g_pt[64], const uint8_t h_pt[64],
+                   const uint8_t P_xy[64], const uint8_t y_be[32], const uint8_t* arg, size_t arg_len, int mode, uint8_t* verdict);
 
 /* Per-kernel device timing with HIP events on the context's own stream (what bench.py's roofline
  * block reads; no reference counterpart).  Kernel ids: 0 = bpv_decompress, 1 = bpv_scalars,

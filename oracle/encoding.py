@@ -98,3 +98,14 @@ def decode_bpplus(b):
     a_tag, b_tag = pt(), pt()
     r_prime, s_prime, delta_prime = sc(), sc(), sc()
     return RangeProofWIP(A, WeightedInnerProdArg(L, R, a_tag, b_tag, r_prime, s_prime, delta_prime))
+
+
+def encode_ipa(ipp):
+    """Standalone InnerProductArg (inner_product.rs:28-33): L_1..L_k | R_1..R_k | a_tag b_tag = 66k + 64 bytes (the tail of the BP encoding)."""
+    return b"".join([ec.compress(x) for x in ipp.L] + [ec.compress(x) for x in ipp.R] + [_s(ipp.a_tag), _s(ipp.b_tag)])
+
+
+def encode_wipa(w):
+    """Standalone WeightedInnerProdArg (weighted_inner_product.rs:36-44): L[k] | R[k] | a_tag b_tag (points) | r' s' delta' = 66k + 162 bytes."""
+    return b"".join([ec.compress(x) for x in w.L] + [ec.compress(x) for x in w.R] + [ec.compress(w.a_tag), ec.compress(w.b_tag),
+                                                                                      _s(w.r_prime), _s(w.s_prime), _s(w.delta_prime)])

@@ -100,6 +100,12 @@ extern "C" {
     pub fn bp_rangeproof_verify_batch_device(ctx: *mut bp_ctx, gens: *const bp_gens, n_bits: c_int, m: c_int, d_proofs: *const c_void,
                                              proof_len: usize, d_coms_xy: *const c_void, nproofs: usize,
                                              d_verdicts: *mut c_void) -> c_int;
+    // aggregated_verify x N with a different m per proof (range_proof.rs:537-782, range_proof_wip.rs:388-609)
+    pub fn bp_rangeproof_verify_batch_mixed(ctx: *mut bp_ctx, gens: *const bp_gens, n_bits: c_int, proofs: *const u8, proof_off: *const usize,
+                                            coms_xy: *const u8, m_per_proof: *const u32, nproofs: usize, verdicts: *mut u8) -> c_int;
+    pub fn bp_wip_rangeproof_verify_batch_mixed(ctx: *mut bp_ctx, gens: *const bp_gens, n_bits: c_int, proofs: *const u8,
+                                                proof_off: *const usize, coms_xy: *const u8, m_per_proof: *const u32, nproofs: usize,
+                                                verdicts: *mut u8) -> c_int;
     // no counterpart in the reference: the same call for callers that cannot allocate (fixed 64 MiB device scratch per GPU)
     pub fn bp_rangeproof_verify_batch_device_noalloc(ctx: *mut bp_ctx, gens: *const bp_gens, n_bits: c_int, m: c_int,
                                                      d_proofs: *const c_void, proof_len: usize, d_coms_xy: *const c_void, nproofs: usize,
@@ -111,6 +117,18 @@ extern "C" {
     pub fn bp_rangeproof_verify_batch_rlc_device(ctx: *mut bp_ctx, gens: *const bp_gens, n_bits: c_int, m: c_int,
                                                  d_proofs: *const c_void, proof_len: usize, d_coms_xy: *const c_void, nproofs: usize,
                                                  seed: *const u8, d_verdicts: *mut c_void, used_fallback: *mut c_int) -> c_int;
+
+    // InnerProductArg::{prove, verify, fast_verify} (inner_product.rs:36, 171, 253) and WeightedInnerProdArg::{prove, verify,
+    // fast_verify} (weighted_inner_product.rs:47, 270, 386) over caller-supplied bases
+    pub fn bp_ipa_prove(ctx: *mut bp_ctx, g_xy: *const u8, h_xy: *const u8, n: usize, ux_xy: *const u8, p_xy: *const u8, a_be: *const u8,
+                        b_be: *const u8, arg_out: *mut u8, arg_cap: usize, arg_len: *mut usize) -> c_int;
+    pub fn bp_ipa_verify(ctx: *mut bp_ctx, g_xy: *const u8, hi_tag_xy: *const u8, n: usize, ux_xy: *const u8, p_xy: *const u8,
+                         arg: *const u8, arg_len: usize, mode: c_int, verdict: *mut u8) -> c_int;
+    pub fn bp_wipa_prove(ctx: *mut bp_ctx, g_xy: *const u8, h_xy: *const u8, n: usize, g_pt: *const u8, h_pt: *const u8, p_xy: *const u8,
+                         a_be: *const u8, b_be: *const u8, alpha_be: *const u8, y_be: *const u8, tape: *const u8, tape_len: usize,
+                         arg_out: *mut u8, arg_cap: usize, arg_len: *mut usize) -> c_int;
+    pub fn bp_wipa_verify(ctx: *mut bp_ctx, g_xy: *const u8, hi_tag_xy: *const u8, n: usize, g_pt: *const u8, h_pt: *const u8,
+                          p_xy: *const u8, y_be: *const u8, arg: *const u8, arg_len: usize, mode: c_int, verdict: *mut u8) -> c_int;
 
     // RangeProofWIP::{prove, verify, aggregated_verify} (range_proof_wip.rs:101-609)
     pub fn bp_wip_rangeproof_prove(ctx: *mut bp_ctx, gens: *const bp_gens, n_bits: c_int, secrets_be: *const u8, blindings_be: *const u8,

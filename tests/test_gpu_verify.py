@@ -325,3 +325,83 @@ def test_bpplus_rlc_many_distinct_and_malformed(ctx, oracle_c):
         assert got == ctx.wip_rangeproof_verify_batch(gens, n, m, b"".join(bad), b"".join(coms))
     finally:
         gens.close()
+
+
+def _items(case):
+    out = [(bytes.fromhex(case["proof"]), b"".join(bytes.fromhex(c) for c in case["commitments"]), VERDICT_CODE[case.get("verdict", "Ok")])]
+    for t in case["tampered"]:
+        out.append((bytes.fromhex(t["proof"]), b"".join(bytes.fromhex(c) for c in t["commitments"]), VERDICT_CODE[t["verdict"]]))
+    return out
+
+
+def test_bp_mixed_aggregation_sizes_in_one_call(ctx):
+    """bp_rangeproof_verify_batch_mixed (proof_off[] + m_per_proof[]): n=64 proofs with m = 1, 4 and 16 over ONE
+    bp_gens of the largest size (each proof uses the generator prefixes a caller of the reference would slice,
+    range_proof.rs:556-557), interleaved, honest / tampered / malformed: verdicts == the oracle's fixture verdicts ==
+    the per-proof path with generators of each proof's own size."""
+    b = load("bp_c3_batch_n64_m1.json")
+    plen1 = 292 + 66 * 6
+    c3 = [(bytes.fromhex(b["proofs"])[i * plen1:(i + 1) * plen1], bytes.fromhex(b["commitments"])[i * 64:(i + 1) * 64], 0) for i in range(5)]
+    sets = {1: _items(bp_cases()[3]) + c3, 4: _items(bp_cases()[4]), 16: _items(load("bp_c2_n64_m16.json"))}
+    order = []
+    for i in range(max(len(v) for v in sets.values())):
+        for m in (4, 16, 1):
+            if i < len(sets[m]):
+                order.append((m,) + sets[m][i])
+    gens = _gens(ctx, 64, 16, window_bits=7)
+    try:
+        got = ctx.rangeproof_verify_batch_mixed(gens, 64, [o[1] for o in order], [o[0] for o in order], b"".join(o[2] for o in order))
+        assert got == [o[3] for o in order]
+        assert {0, 3, 255} <= set(got)
+        # m-homogeneous calls on a prefix of the same gens give the same bytes as gens of the exact size
+        small = _gens(ctx, 64, 1, window_bits=7)
+        try:
+            for m, pf, cm, want in order:
+                if m == 1:
+                    assert ctx.rangeproof_verify(small, 64, 1, pf, cm, 2) == want
+        finally:
+            small.close()
+        with pytest.raises(bpa.BpError):   # m = 32 exceeds the generators: the reference's assert_eq!(g_vec.len(), nm)
+            ctx.rangeproof_verify_batch_mixed(gens, 64, [order[0][1]], [32], order[0][2] * 32)
+        with pytest.raises(bpa.BpError):   # proof length does not match its m
+            ctx.rangeproof_verify_batch_mixed(gens, 64, [sets[4][0][0]], [1], sets[4][0][1][:64])
+        assert ctx.rangeproof_verify_batch_mixed(gens, 64, [], [], b"") == []
+    finally:
+        gens.close()
+
+
+def test_bpplus_mixed_aggregation_sizes_in_one_call(ctx, oracle_c):
+    """bp_wip_rangeproof_verify_batch_mixed: Bulletproofs+ n=16 proofs with m = 1, 2, 4 (GPU-made, pinned by
+    test_gpu_proto.py) + the golden n=16 m=2 case with its tampered variants, one call over the m=4 generators; verdicts ==
+    the per-proof path with generators of each proof's own size == the oracle's on the golden ones."""
+    from oracle import tape
+    from _golden import bpplus_cases
+    n = 16
+    items = []
+    per_m_gens = {}
+    for m in (1, 2, 4):
+        g, h, G, H = bpa.generate_bases(1, bpa.KZEN_SEED, n, m)
+        per_m_gens[m] = bpa.Gens(ctx, g, h, G, H, 6)
+        k = (n * m).bit_length() - 1
+        for t in range(3):
+            tb = tape.make_tape_bytes("mixplus-%d-%d" % (m, t), m + 1 + 2 * k + 4)
+            secs = b"".join(((t * 977 + j * 31 + 5) % (1 << n)).to_bytes(32, "big") for j in range(m))
+            pf = ctx.wip_rangeproof_prove(per_m_gens[m], n, secs, tb[:32 * m], tb[32 * m:])
+            cm = b"".join(ctx.msm(G + H, secs[32 * j:32 * j + 32] + tb[32 * j:32 * j + 32], None) for j in range(m))
+            if t == 2:
+                pf = pf[:-1] + bytes([pf[-1] ^ 1])
+            items.append((m, pf, cm))
+    case = bpplus_cases()[1]
+    assert (case["n"], case["m"]) == (16, 2)
+    gold = _items(case)
+    items += [(2, pf, cm) for pf, cm, _ in gold]
+    try:
+        want = [ctx.wip_rangeproof_verify(per_m_gens[m], n, m, pf, cm, 2) for m, pf, cm in items]
+        assert want[-len(gold):] == [v for _, _, v in gold]
+        assert want[:9] == [0, 0, 3] * 3
+        got = ctx.rangeproof_verify_batch_mixed(per_m_gens[4], n, [it[1] for it in items], [it[0] for it in items], b"".join(it[2] for it in items),
+                                                wip=True)
+        assert got == want
+    finally:
+        for g in per_m_gens.values():
+            g.close()
