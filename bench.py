@@ -39,10 +39,13 @@ MAD32_PER_PROOF_TOTAL = 6.60e6      # + the two fixed-base multiplications y*G, 
 # figure was 9.83e12; the measured one is the denominator used here).
 PEAK_MAD32_PER_S = 31.2e12
 MAD32_PER_POINT_MSM = 11833.0       # SURVEY.md 8(d), C5 model (2^20 points, c = 16)
-# Executed v_mad_u64_u32 lane-results per unit, counted by the instrumented build (scripts/opcount.py ->
-# profiles/r02_opcount.json): field multiplications x 91 + squarings x 55 (static counts of fp_mul / fp_sqr, fp.h).
-EXEC_MAD32_PER_PROOF_MSM = 2.40e6   # k_bpv_msm, n=64 m=1, 20-bit table, 2 lanes per proof  (placeholder until measured)
-EXEC_MAD32_PER_POINT_MSM = None     # whole bp_msm_device pipeline at 2^20 points
+# Executed v_mad_u64_u32 lane-results per unit, COUNTED by the instrumented build (scripts/opcount.py ->
+# profiles/r02_opcount.json: every lane counts its fp_mul / fp_sqr calls) x the static v_mad_u64_u32 count of one call
+# (fp_mul 102, fp_sqr 65 incl. the reduction, profiles/r02_fp_isa.txt):
+#   k_bpv_msm, n=64 m=1, 20-bit table, 2 lanes per proof: 23 900 fp_mul + 7 223 fp_sqr per proof
+#   whole bp_msm_device pipeline at 2^20 points:           157.0 fp_mul + 39.4 fp_sqr per point
+EXEC_MAD32_PER_PROOF_MSM = 2.907e6
+EXEC_MAD32_PER_POINT_MSM = 18578.0
 # HBM-side traffic of one k_bpv_msm launch at the default configuration (65536 proofs, auto lanes, 20-bit table
 # windows), from the separate --pmc passes in profiles/r01_pmc_read.csv / r01_pmc_write.csv:
 # TCC_EA0_RDREQ 143.80e6 x 64 B (64-byte gathers of table entries and lane-private window tables, not the
@@ -497,8 +500,10 @@ def msm_side(ctx, dev, log2n, steps):
             "what": "bp_msm_device, one call at a time, inputs resident in HBM, 64-byte result returned to the host",
             "roofline": {"bound": "valu_int32_mad", "kernel": "whole bp_msm_device pipeline (dominant kernel k_srt_acc)",
                          "achieved": mpts * 1e6 * MAD32_PER_POINT_MSM / 1e12, "peak": PEAK_MAD32_PER_S / 1e12, "unit": "TMAD32/s",
-                         "frac": mpts * 1e6 * MAD32_PER_POINT_MSM / PEAK_MAD32_PER_S, "frac_model": mpts * 1e6 * MAD32_PER_POINT_MSM / PEAK_MAD32_PER_S,
-                         "frac_executed": (mpts * 1e6 * EXEC_MAD32_PER_POINT_MSM / PEAK_MAD32_PER_S) if EXEC_MAD32_PER_POINT_MSM else None,
+                         "frac": mpts * 1e6 * (EXEC_MAD32_PER_POINT_MSM if log2n == 20 else MAD32_PER_POINT_MSM) / PEAK_MAD32_PER_S,
+                         "frac_model": mpts * 1e6 * MAD32_PER_POINT_MSM / PEAK_MAD32_PER_S,
+                         "frac_executed": (mpts * 1e6 * EXEC_MAD32_PER_POINT_MSM / PEAK_MAD32_PER_S) if log2n == 20 else None,
+                         "executed_mad32_per_point": EXEC_MAD32_PER_POINT_MSM if log2n == 20 else None, "model_mad32_per_point": MAD32_PER_POINT_MSM,
                          "traffic": None}}
 
 
@@ -754,7 +759,9 @@ def main():
         value = total_proofs / dt
         msm_ms = kms["bpv_msm"]
         model = MAD32_PER_PROOF_MSM * P / (msm_ms * 1e-3) if msm_ms > 0 else 0.0
-        executed = EXEC_MAD32_PER_PROOF_MSM * P / (msm_ms * 1e-3) if msm_ms > 0 else 0.0
+        # the counted figure belongs to the default configuration (>= 65536 proofs per launch: 2 lanes per proof; automatic table window)
+        counted = P >= 65536 and not args.window_bits and not args.lanes and msm_ms > 0
+        executed = EXEC_MAD32_PER_PROOF_MSM * P / (msm_ms * 1e-3) if counted else model
         by_count = {r["proofs_per_launch_per_gpu"]: r for r in sweep}
         out = {
             "metric": "verified range proofs/sec (secp256k1, n=64) at 1/2/4/8 GPUs; MSM Mpts/s",
@@ -792,11 +799,11 @@ def main():
                 "peak": PEAK_MAD32_PER_S / 1e12,
                 "unit": "TMAD32/s",
                 "frac": executed / PEAK_MAD32_PER_S,
-                "frac_executed": executed / PEAK_MAD32_PER_S,
+                "frac_executed": executed / PEAK_MAD32_PER_S if counted else None,
                 "frac_model": model / PEAK_MAD32_PER_S,
                 "traffic": PMC_TRAFFIC_BYTES_DEFAULT if (P == 65536 and not args.window_bits and not args.lanes) else None,
                 "traffic_unit": "bytes per launch (PMC, profiles/r02_pmc_*.csv)",
-                "executed_mad32_per_proof": EXEC_MAD32_PER_PROOF_MSM,
+                "executed_mad32_per_proof": EXEC_MAD32_PER_PROOF_MSM if counted else None,
                 "model_mad32_per_proof": MAD32_PER_PROOF_MSM,
                 "what": "frac = frac_executed: v_mad_u64_u32 lane-results the kernel executes per proof (counted by the instrumented build, "
                         "profiles/r02_opcount.json: field multiplications x 91 + squarings x 55) x proofs / launch time / measured peak; "

@@ -71,7 +71,8 @@ class BpError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libbpmsm.so")
+    # BPMSM_LIB selects another build of the same library (scripts/opcount.py loads the instrumented libbpmsm_opcount.so)
+    return os.environ.get("BPMSM_LIB") or os.path.join(_HERE, "libbpmsm.so")
 
 
 _lib = None

@@ -48,6 +48,39 @@
 #define BP_OPAQUE(x) ((void)0)
 #endif
 
+// Instrumented build only (-DBP_OPCOUNT, `make opcount` -> libbpmsm_opcount.so; scripts/opcount.py): every lane counts the
+// field multiplications and squarings it executes, so that bench.py's `frac_executed` is a counted number, not a model.
+// The arrays are file-local: a translation unit that wants its count read back instantiates BP_OPCOUNT_READER(name).
+#if defined(BP_OPCOUNT) && defined(__HIPCC__)
+#define BP_OPCOUNT_SLOTS (1 << 18)
+static __device__ unsigned int bp_oc_mul[BP_OPCOUNT_SLOTS], bp_oc_sqr[BP_OPCOUNT_SLOTS];
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BP_COUNT(arr) atomicAdd(&arr[(blockIdx.x * blockDim.x + threadIdx.x) & (BP_OPCOUNT_SLOTS - 1)], 1u)
+#else
+#define BP_COUNT(arr) ((void)0)
+#endif
+#define BP_OPCOUNT_READER(name)                                                                              \
+    extern "C" int name(unsigned long long* mul, unsigned long long* sqr, int reset) {                       \
+        static unsigned int h[BP_OPCOUNT_SLOTS];                                                             \
+        unsigned long long m = 0, q = 0;                                                                     \
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(bp_oc_mul), sizeof h) != hipSuccess) return -3;                \
+        for (int i = 0; i < BP_OPCOUNT_SLOTS; i++) m += h[i];                                                \
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(bp_oc_sqr), sizeof h) != hipSuccess) return -3;                \
+        for (int i = 0; i < BP_OPCOUNT_SLOTS; i++) q += h[i];                                                \
+        if (reset) {                                                                                         \
+            for (int i = 0; i < BP_OPCOUNT_SLOTS; i++) h[i] = 0;                                             \
+            if (hipMemcpyToSymbol(HIP_SYMBOL(bp_oc_mul), h, sizeof h) != hipSuccess) return -3;              \
+            if (hipMemcpyToSymbol(HIP_SYMBOL(bp_oc_sqr), h, sizeof h) != hipSuccess) return -3;              \
+        }                                                                                                    \
+        *mul = m;                                                                                            \
+        *sqr = q;                                                                                            \
+        return 0;                                                                                            \
+    }
+#else
+#define BP_COUNT(arr) ((void)0)
+#define BP_OPCOUNT_READER(name)
+#endif
+
 namespace bp {
 
 struct fp {
@@ -170,6 +203,7 @@ BP_HD void fp_fold_top(fp& o, uint64_t c, uint32_t h8) {
 // 81 + 17 MADs.  (The multiplication by 256 goes through the multiplier on purpose: as a 64-bit
 // shift-and-add it costs two instructions and a register pair with a zeroed high half.)
 BP_HD_MUL fp fp_mul(fp a, fp b) {
+    BP_COUNT(bp_oc_mul);
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         BP_OPAQUE(a.v[i]);
@@ -204,6 +238,7 @@ BP_HD_MUL fp fp_mul(fp a, fp b) {
 
 // Squaring: 45 MADs (off-diagonal terms use a doubled operand) + 17 in the fold.
 BP_HD_MUL fp fp_sqr(fp a) {
+    BP_COUNT(bp_oc_sqr);
 #pragma unroll
     for (int i = 0; i < 9; i++) BP_OPAQUE(a.v[i]);
     uint32_t k256 = 256u;

@@ -437,3 +437,5 @@ hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine_mem* i
 }
 
 }  // namespace bp
+
+BP_OPCOUNT_READER(bp_opcount_msm_kernels)

@@ -414,3 +414,5 @@ hipError_t launch_msm_sorted(const affine_mem* pts, const affine_mem* lam, size_
 }
 
 }  // namespace bp
+
+BP_OPCOUNT_READER(bp_opcount_msm_sorted)

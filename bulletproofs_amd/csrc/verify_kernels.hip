@@ -215,3 +215,5 @@ hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, cons
 }
 
 }  // namespace bp
+
+BP_OPCOUNT_READER(bp_opcount_verify)
