@@ -23,6 +23,7 @@
 
 #include "../../include/bpmsm.h"
 #include "ctx.h"
+#include "fbbatcher.h"
 #include "hostmath.h"
 #include "kernels.h"
 
@@ -263,61 +264,13 @@ int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_i
 }
 
 // Batch provers (bp_rangeproof_prove_batch): N proofs run the unchanged single-proof code on N host threads; their
-// table-MSM calls meet here and go to the GPU as ONE launch per protocol step (all proofs of a batch take the same
-// steps: same n, m), so a batch costs as many launches and synchronisations as one proof while the per-proof scalar
-// work (host, as in the reference) runs on all cores.  The last thread to arrive performs the launch for everyone.
-struct FbBatcher {
-    bp_ctx* ctx;
-    const bp_gens* g;
-    std::mutex mu;
-    std::condition_variable cv;
-    int active = 0, waiting = 0;
-    uint64_t gen = 0;
-    int rc = BP_OK;
-    std::vector<const std::vector<FbJob>*> pj;
-    std::vector<Pt*> po;
-
-    void flush_locked() {  // mu held; every active thread is waiting
-        try {
-            std::vector<const FbJob*> all;
-            for (auto* v : pj)
-                for (auto& j : *v) all.push_back(&j);
-            const size_t total = all.size();
-            std::vector<Pt> res(total);
-            static const std::vector<FbJob> none;
-            rc = total ? fbmsm_direct(ctx, g, none, res.data(), &all) : BP_OK;
-            if (rc == BP_OK) {
-                size_t o = 0;
-                for (size_t i = 0; i < pj.size(); i++)
-                    for (size_t j = 0; j < pj[i]->size(); j++) po[i][j] = res[o++];
-            }
-        } catch (...) {  // host allocation failure: every proof of this step fails, none is left waiting
-            rc = BP_ENOMEM;
-        }
-        pj.clear();
-        po.clear();
-        waiting = 0;
-        gen++;
-        cv.notify_all();
-    }
-    int submit(const std::vector<FbJob>& jobs, Pt* out) {
-        std::unique_lock<std::mutex> lk(mu);
-        pj.push_back(&jobs);
-        po.push_back(out);
-        waiting++;
-        if (waiting == active) {
-            flush_locked();
-            return rc;
-        }
-        const uint64_t my = gen;
-        cv.wait(lk, [&] { return gen != my; });
-        return rc;
-    }
-    void leave() {  // a proof finished (or failed): the others must not wait for it
-        std::unique_lock<std::mutex> lk(mu);
-        active--;
-        if (waiting > 0 && waiting == active) flush_locked();
-    }
+// table-MSM calls meet in a StepRendezvous (fbbatcher.h) and go to the GPU as ONE launch per protocol step.
+struct FbBatcher : StepRendezvous<FbJob, Pt> {
+    FbBatcher(bp_ctx* ctx, const bp_gens* g)
+        : StepRendezvous<FbJob, Pt>([ctx, g](const std::vector<const FbJob*>& all, Pt* res) {
+              static const std::vector<FbJob> none;
+              return fbmsm_direct(ctx, g, none, res, &all);
+          }) {}
 };
 thread_local FbBatcher* tl_batcher = nullptr;
 
@@ -1738,9 +1691,7 @@ static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
     std::vector<int> st(nproofs, BP_OK);
     for (size_t base = 0; base < nproofs; base += kChunk) {
         const size_t cnt = nproofs - base < kChunk ? nproofs - base : kChunk;
-        FbBatcher b;
-        b.ctx = ctx;
-        b.g = gens;
+        FbBatcher b(ctx, gens);
         b.active = (int)cnt;
         b.pj.reserve(cnt);  // submit() then never allocates
         b.po.reserve(cnt);

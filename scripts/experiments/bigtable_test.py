@@ -1,7 +1,7 @@
 """Does a fixed-base table of tens of GiB slow the gathers of k_bpv_msm down?  n=64 m=16 (np = 2050) proofs,
 distinct challenges per proof (different tx bits), table windows 12 (5.9 GiB) / 14 / 16 (73 GiB)."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bulletproofs_amd as bpa
 

@@ -1,6 +1,6 @@
 """A few 2^20 MSMs through the C ABI (timeline runs under rocprofv3 --kernel-trace)."""
 import hashlib, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bulletproofs_amd as bpa
 log2 = int(sys.argv[1]) if len(sys.argv) > 1 else 20

@@ -1,5 +1,5 @@
 import hashlib, threading, time, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bulletproofs_amd as bpa
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)

@@ -1,8 +1,8 @@
 """A few C1 proves through the C ABI (timeline runs under rocprofv3 --kernel-trace)."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bulletproofs_amd as bpa
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 case = json.load(open(os.path.join(ROOT, "tests", "golden", "bp_cases.json")))[3]
 be = lambda xs: b"".join(int(x, 16).to_bytes(32, "big") for x in xs)
 ctx = bpa.Context(0)

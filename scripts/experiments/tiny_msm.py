@@ -1,6 +1,6 @@
 """Latency of tiny bp_msm calls (2, 8, 64 terms) through the C ABI."""
 import os, sys, time, hashlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bulletproofs_amd as bpa
 ctx = bpa.Context(0)
 sc = lambda i: hashlib.sha256(b"tiny-%d" % i).digest()

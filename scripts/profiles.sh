@@ -14,7 +14,7 @@ timeout -s KILL 200 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $
 timeout -s KILL 200 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d $O/msm_pmc_wr -o pmc -- python3 bench.py --workload msm --steps 3 --warmup 1 > $O/msm_pmc_wr.json 2> $O/msm_pmc_wr.err
 timeout -k 10 300 python3 bench.py --workload msm --msm-log2 22 --steps 5 > $O/msm_bench_2p22.json 2>> $O/msm.err
 timeout -k 10 300 python3 bench.py --workload prove --steps 8 > $O/prove_latency.json 2> $O/prove.err
-timeout -k 10 300 python3 scratch/bigtable_test.py 4096 12,14,16 > $O/bigtable.txt 2> $O/bigtable.err
+timeout -k 10 300 python3 scripts/experiments/bigtable_test.py 4096 12,14,16 > $O/bigtable.txt 2> $O/bigtable.err
 timeout -k 10 120 ./bench_micro/ecops > $O/ecops.jsonl 2> $O/ecops.err
 timeout -k 10 120 ./bench_micro/peak_mad32 > $O/peak_mad32.jsonl 2> $O/peak.err
 for d in kt pmc_rd pmc_wr pmc_valu msm_kt msm_pmc_rd msm_pmc_wr; do f=$(ls $O/$d/*_results.db); m=pmc; case $d in kt|msm_kt) m=stats;; esac; python3 profiles/summarize.py $m $f $O/$d.csv; done

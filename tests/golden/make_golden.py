@@ -151,11 +151,35 @@ def make_bpplus(n, m, seed):
     t = bytearray(b); t[-1] ^= 1; tam.append(("flip_delta_prime_bit", bytes(t), com))
     t = bytearray(b); t[33 + 66 * k + 66 + 31] ^= 1; tam.append(("flip_r_prime_bit", bytes(t), com))
     c2 = list(com); c2[-1] = ec.add(c2[-1], ec.G); tam.append(("commitment_plus_G", b, c2))
+    # swap L_1 and R_1 / a_tag and b_tag (still valid points, wrong statement)
+    t = bytearray(b); t[33:66], t[33 + 33 * k:66 + 33 * k] = b[33 + 33 * k:66 + 33 * k], b[33:66]; tam.append(("swap_L1_R1", bytes(t), com))
+    o = 33 + 66 * k
+    t = bytearray(b); t[o:o + 33], t[o + 33:o + 66] = b[o + 33:o + 66], b[o:o + 33]; tam.append(("swap_a_tag_b_tag", bytes(t), com))
+    # malformed: A's x coordinate not on the curve / scalar >= q
+    t = bytearray(b)
+    x = int.from_bytes(t[1:33], "big")
+    while True:
+        x = (x + 1) % ec.P
+        try:
+            ec.decompress(bytes([2]) + x.to_bytes(32, "big"))
+        except ValueError:
+            break
+    t[1:33] = x.to_bytes(32, "big"); tam.append(("A_not_on_curve", bytes(t), com))
+    t = bytearray(b); t[o + 66:o + 98] = (ec.Q + 5).to_bytes(32, "big"); tam.append(("r_prime_ge_q", bytes(t), com))
+    t = bytearray(b); t[o + 33] = 4; tam.append(("b_tag_bad_prefix", bytes(t), com))
     tampered = []
     for name, pb, cc in tam:
-        p2 = encoding.decode_bpplus(pb)
-        tampered.append({"name": name, "proof": hx(pb), "commitments": [hx(ec.enc64(c)) for c in cc],
-                         "verdict": p2.aggregated_verify(stmt, cc)})
+        try:
+            p2 = encoding.decode_bpplus(pb)
+            w = p2.weighted_inner_product_proof
+            if any(s >= ec.Q for s in (w.r_prime, w.s_prime, w.delta_prime)):
+                raise ValueError("scalar >= q")
+            verdict = p2.aggregated_verify(stmt, cc)
+            if n * m <= 128:
+                assert p2.verify(stmt, cc) == verdict
+        except ValueError:
+            verdict = "Malformed"
+        tampered.append({"name": name, "proof": hx(pb), "commitments": [hx(ec.enc64(c)) for c in cc], "verdict": verdict})
     out["tampered"] = tampered
     return out
 
@@ -172,16 +196,18 @@ def main():
     with open(os.path.join(HERE, "kats.json"), "w") as f:
         json.dump(kats, f, indent=1)
 
+    plus_only = "--plus-only" in sys.argv  # regenerate only the Bulletproofs+ fixtures (same seeds: same proofs)
     cases = []
-    for (n, m, seed) in [(8, 1, "t8x1"), (16, 2, "t16x2"), (32, 4, "t32x4"), (64, 1, "c1"), (64, 4, "t64x4")]:
+    for (n, m, seed) in [] if plus_only else [(8, 1, "t8x1"), (16, 2, "t16x2"), (32, 4, "t32x4"), (64, 1, "c1"), (64, 4, "t64x4")]:
         print("bp", n, m, flush=True)
         cases.append(bp_case(n, m, seed))
-    with open(os.path.join(HERE, "bp_cases.json"), "w") as f:
-        json.dump(cases, f)
+    if not plus_only:
+        with open(os.path.join(HERE, "bp_cases.json"), "w") as f:
+            json.dump(cases, f)
 
-    print("bp 64x16 (config C2)", flush=True)
-    with open(os.path.join(HERE, "bp_c2_n64_m16.json"), "w") as f:
-        json.dump(bp_case(64, 16, "c2"), f)
+        print("bp 64x16 (config C2)", flush=True)
+        with open(os.path.join(HERE, "bp_c2_n64_m16.json"), "w") as f:
+            json.dump(bp_case(64, 16, "c2"), f)
 
     print("bp+ cases", flush=True)
     plus = [make_bpplus(n, m, s) for (n, m, s) in [(8, 1, "p8x1"), (16, 2, "p16x2"), (32, 4, "p32x4"), (64, 4, "p64x4")]]
@@ -192,6 +218,9 @@ def main():
     with open(os.path.join(HERE, "bpplus_c4_n64_m64.json"), "w") as f:
         json.dump(make_bpplus(64, 64, "c4"), f)
 
+    if plus_only:
+        print("done (plus only)")
+        return
     # C3 batch: 256 distinct n=64 m=1 proofs with the shared generators (bench.py tiles them)
     print("c3 batch", flush=True)
     with mp.Pool(8) as pool:

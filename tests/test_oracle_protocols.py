@@ -134,6 +134,13 @@ def test_bpplus_golden(oracle_c, idx):
     com = [ec.dec64(bytes.fromhex(c)) for c in case["commitments"]]
     assert proof.verify(stmt, com) == "Ok" == proof.aggregated_verify(stmt, com)
     for t in case["tampered"]:
-        p2 = encoding.decode_bpplus(bytes.fromhex(t["proof"]))
         c2 = [ec.dec64(bytes.fromhex(c)) for c in t["commitments"]]
-        assert p2.aggregated_verify(stmt, c2) == t["verdict"] == p2.verify(stmt, c2)
+        try:
+            p2 = encoding.decode_bpplus(bytes.fromhex(t["proof"]))
+            w = p2.weighted_inner_product_proof
+            if any(s >= ec.Q for s in (w.r_prime, w.s_prime, w.delta_prime)):
+                raise ValueError("scalar >= q")
+        except ValueError:  # a point off the curve / a scalar >= q: curv would not deserialise it
+            assert t["verdict"] == "Malformed", t["name"]
+            continue
+        assert p2.aggregated_verify(stmt, c2) == t["verdict"] == p2.verify(stmt, c2), t["name"]
