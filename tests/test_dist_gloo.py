@@ -54,15 +54,24 @@ def _worker(rank, world, port, q):
     pts = [ec.mul(ec.G, rng.randrange(1, ec.Q)) for _ in range(11)]
     ks = [rng.randrange(ec.Q) for _ in range(11)]
 
-    # stand-ins with the shapes of ctx.msm_partial_device / ctx.msm_combine: a "partial" here is one encoded point
+    # the product's byte format across the processes: every rank's partial is a bp_msm_partial_bytes(c)-sized buffer of W XYZZ
+    # window sums (tests/_partial.py; tied to the library by tests/test_gpu_msm.py), all-gathered by msm_sharded exactly as
+    # bench.py --workload msm does with ctx.msm_partial_device / ctx.msm_combine; the oracle stands in for the two GPU calls
+    import bulletproofs_amd as bpa
+    import _partial
+    c = 7
+    ks = [k >> 128 for k in ks]  # < 2^128: unsigned c-bit digits fit the W = (129 + c) // c windows of the format
+    psize = bpa.lib().bp_msm_partial_bytes(c)
+    assert psize == _partial.windows(c) * _partial.XYZZ_BYTES
+
     def partial_fn(lo_, hi_):
-        return ec.enc64(ec.msm_naive(pts[lo_:hi_], ks[lo_:hi_], None))
+        part = _partial.encode_partial(_partial.unsigned_window_sums(pts[lo_:hi_], ks[lo_:hi_], c), c)
+        assert len(part) == psize
+        return part
 
     def combine_fn(parts, g):
-        acc = None
-        for i in range(g):
-            acc = ec.add(acc, ec.dec64(parts[64 * i:64 * i + 64]))
-        return ec.enc64(acc)
+        assert len(parts) == g * psize
+        return ec.enc64(_partial.combine(parts, g, c))
 
     msm_got = batch.msm_sharded(len(pts), partial_fn, combine_fn)
     msm_ok = msm_got == ec.enc64(ec.msm_naive(pts, ks, None))

@@ -236,3 +236,24 @@ def test_msm_window_partials_combine(ctx, oracle_c, shards):
         parts += ctx.msm_partial(*_pack(pts[lo:lo + sz], ks[lo:lo + sz]), c)
         lo += sz
     assert ctx.msm_combine(parts, len(shards), c, ec.enc64(init)) == want
+
+
+def test_msm_partial_byte_format(ctx, oracle_c):
+    """The partial buffers that cross the process boundary (bench.py --workload msm, tests/test_dist_gloo.py): tests/_partial.py
+    reads real bp_msm_partial output (Horner-combined by the oracle == bp_msm) and bp_msm_combine reads partials written by
+    tests/_partial.py (== the oracle's MSM), so the gloo test's stand-in buffers are the product's format."""
+    import bulletproofs_amd as bpa
+    import _partial
+    rng = random.Random(4242)
+    n, c = 150, 7
+    pts = _rand_points(rng, n, oracle_c)
+    ks = [rng.randrange(ec.Q) for _ in range(n)]
+    assert bpa.lib().bp_msm_partial_bytes(c) == _partial.windows(c) * _partial.XYZZ_BYTES
+    want = oracle_c.msm_naive(pts, ks, None)
+    parts = ctx.msm_partial(*_pack(pts[:90], ks[:90]), c) + ctx.msm_partial(*_pack(pts[90:], ks[90:]), c) + ctx.msm_partial(b"", b"", c)
+    assert _partial.combine(parts, 3, c) == want
+    assert ctx.msm_combine(parts, 3, c) == ec.enc64(want)
+    small = [k >> 130 for k in ks]
+    enc = _partial.encode_partial(_partial.unsigned_window_sums(pts[:70], small[:70], c), c) + \
+        _partial.encode_partial(_partial.unsigned_window_sums(pts[70:], small[70:], c), c)
+    assert ctx.msm_combine(enc, 2, c) == ec.enc64(oracle_c.msm_naive(pts, small, None))
