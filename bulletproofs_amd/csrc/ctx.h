@@ -55,7 +55,7 @@ struct bp_ctx {
     bp::DevBuf lam;     // lambda(P_i) = (beta x_i, y_i), the GLV images of the current MSM's points
     bp::DevBuf srt[7];  // sorted-path workspaces (msm_sorted.hip)
     bp::DevBuf scratch[8];
-    bp::DevBuf vartab, fixres;
+    bp::DevBuf vartab, fixres, fixpart;
     bp::DevBuf proto[6];  // protocol layer (proto.cpp): folded bases, hi_tag, staging
     bp::DevBuf rlc[3];    // random-linear-combination batch verifier (rlc_kernels.hip): weights, MSM scalars, misc
     bp::DevBuf fb[3];     // fixed-table MSM of the protocol layer (fbmsm.hip): inputs, digits, partials + output
@@ -75,6 +75,7 @@ struct bp_ctx {
         for (auto& s : scratch) s.release();
         vartab.release();
         fixres.release();
+        fixpart.release();
         for (auto& s : proto) s.release();
         for (auto& s : fb) s.release();
         for (auto& s : rlc) s.release();

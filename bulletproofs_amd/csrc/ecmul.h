@@ -122,29 +122,35 @@ BP_HD xyzz ec_mul_glv_slice(const affine& P, const fq& k, int slice, xyzz* tab) 
 // 128 doublings shared by all of them (each extra point costs only its 66 window additions).  Used by
 // the batched verifier when a lane owns more than one proof-specific point.
 //   loadP(j) -> affine, loadK(j) -> fq   for j < cnt <= PPL
-//   tab: PPL * ECMUL_SLOTS lane-private XYZZ-sized slots, dig: PPL * ECMUL_DIGB lane-private bytes.
+//   tab : PPL * ECMUL_SLOTS lane-private XYZZ-sized slots (table construction: XYZZ multiples + prefix products),
+//   atab: PPL * ECMUL_NT lane-private affine_mem entries (64 bytes each, one cache line: the finished tables),
+//   dig : PPL * ECMUL_DIGB lane-private bytes, WINDOW-major: dig[w * 2 PPL + 2 j + half].
 // The doubling chain runs through Jacobian coordinates (xyzz_dbl_n: 2M + 5S per doubling).
 // The multiples 2P..8P of all the lane's points are brought to AFFINE form with ONE inversion (Montgomery's
 // trick over up to 7 * PPL values of ZZZ; prefix products in the two spare slots of every point), so each of
 // the ~62 window additions per point is a mixed addition (8M + 2S) instead of a full one (12M + 2S):
 // 7 multiplications per entry + 270 for the inversion buy ~250 per point.
-#define ECMUL_DIGB 72   // signed digits of k1 at [0, 33), of k2 at [36, 69)
+// The window loop is software-pipelined: all 2 cnt digits of a window come with one load issued a window ahead, and
+// every table entry is fetched while the previous addition runs (the first one of a window during the four doublings):
+// the lane-private tables of a full launch (hundreds of MB) live in HBM, and at two waves per SIMD a dependent
+// digit -> entry -> addition sequence left the SIMD idle for a memory round trip per addition.
+#define ECMUL_DIGB 72   // per point: 2 x 33 signed digits (k1, k2), padded
 #define ECMUL_SLOTS 10  // per point: 8 table entries + 2 slots (8 field elements) of prefix products
 template <int PPL, class LoadP, class LoadK>
-BP_HD xyzz ec_mul_glv_multi(LoadP loadP, LoadK loadK, int cnt, xyzz* tab, int8_t* dig) {
+BP_HD xyzz ec_mul_glv_multi(LoadP loadP, LoadK loadK, int cnt, xyzz* tab, affine_mem* atab, int8_t* dig) {
+    constexpr int DW = 2 * PPL;  // digit bytes per window
     uint32_t valid = 0;
     fp run = fp_one();
     for (int j = 0; j < cnt; j++) {
         affine P = loadP(j);
-        int8_t* dj = dig + j * ECMUL_DIGB;
         if (affine_is_inf(P)) {
-            for (int w = 0; w < ECMUL_DIGB; w++) dj[w] = 0;
+            for (int w = 0; w < ECMUL_WINS; w++) dig[w * DW + 2 * j] = dig[w * DW + 2 * j + 1] = 0;
             continue;
         }
         valid |= 1u << j;
         xyzz* tj = tab + j * ECMUL_SLOTS;
         fp* pref = reinterpret_cast<fp*>(tj + ECMUL_NT);
-        *reinterpret_cast<affine*>(&tj[0]) = P;
+        atab[j * ECMUL_NT] = affine_store(P);
         xyzz t = xyzz_dbl_affine(P);
         tj[1] = t;
         pref[1] = run;
@@ -161,10 +167,12 @@ BP_HD xyzz ec_mul_glv_multi(LoadP loadP, LoadK loadK, int cnt, xyzz* tab, int8_t
         const uint64_t c1 = ecmul_carry_mask(k1), c2 = ecmul_carry_mask(k2);
         for (int w = 0; w < ECMUL_WINS; w++) {
             int d1 = ecmul_digit(k1, c1, w), d2 = ecmul_digit(k2, c2, w);
-            dj[w] = (int8_t)(n1 ? -d1 : d1);
-            dj[36 + w] = (int8_t)(n2 ? -d2 : d2);
+            dig[w * DW + 2 * j] = (int8_t)(n1 ? -d1 : d1);
+            dig[w * DW + 2 * j + 1] = (int8_t)(n2 ? -d2 : d2);
         }
     }
+    for (int j = cnt; j < PPL; j++)
+        for (int w = 0; w < ECMUL_WINS; w++) dig[w * DW + 2 * j] = dig[w * DW + 2 * j + 1] = 0;
     if (valid) {
         fp inv = fp_inv_var(run);
         for (int j = cnt - 1; j >= 0; j--) {
@@ -179,31 +187,50 @@ BP_HD xyzz ec_mul_glv_multi(LoadP loadP, LoadK loadK, int cnt, xyzz* tab, int8_t
                 affine a;
                 a.x = fp_mul(e.X, fp_sqr(zi));
                 a.y = fp_mul(e.Y, zi3);
-                *reinterpret_cast<affine*>(&tj[i]) = a;
+                atab[j * ECMUL_NT + i] = affine_store(a);
             }
         }
     }
     const fp beta = fp_beta();
+    // the 2 PPL digits of window w as packed bytes (one aligned load: the lane's digit block is 72 PPL bytes)
+    auto load_digits = [&](int w, uint32_t dw[(DW + 3) / 4]) {
+        if (DW >= 4) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(dig + w * DW);
+            for (int i = 0; i < DW / 4; i++) dw[i] = q[i];
+        } else {
+            dw[0] = *reinterpret_cast<const uint16_t*>(dig + w * DW);
+        }
+    };
+    auto digit_of = [&](const uint32_t dw[(DW + 3) / 4], int t) { return (int)(int8_t)(dw[t >> 2] >> (8 * (t & 3))); };
+    // (a zero digit fetches entry 0 and ignores it: no branch around the load, nothing uninitialised)
+    auto fetch = [&](int d, int t, affine_mem& e) { e = atab[(t >> 1) * ECMUL_NT + (d == 0 ? 0 : (d < 0 ? -d : d) - 1)]; };
+    const int nt = 2 * cnt;
+    uint32_t dcur[(DW + 3) / 4], dnext[(DW + 3) / 4];
+    load_digits(ECMUL_WINS - 1, dcur);
     xyzz acc = xyzz_inf();
     for (int w = ECMUL_WINS - 1; w >= 0; w--) {
+        if (w > 0) load_digits(w - 1, dnext);  // in flight during this window
+        int d = digit_of(dcur, 0);
+        affine_mem em;
+        fetch(d, 0, em);  // in flight during the doublings
         if (w != ECMUL_WINS - 1) acc = xyzz_dbl_n(acc, 4);
-        for (int j = 0; j < cnt; j++) {
-            const int8_t* dj = dig + j * ECMUL_DIGB;
-            const xyzz* tj = tab + j * ECMUL_SLOTS;
-            int d1 = dj[w];
-            if (d1 != 0) {
-                affine e = *reinterpret_cast<const affine*>(&tj[(d1 < 0 ? -d1 : d1) - 1]);
-                if (d1 < 0) e.y = fp_neg(e.y);
+        for (int t = 0; t < nt; t++) {
+            int dn = 0;
+            affine_mem en = em;
+            if (t + 1 < nt) {
+                dn = digit_of(dcur, t + 1);
+                fetch(dn, t + 1, en);  // in flight during the addition below
+            }
+            if (d != 0) {
+                affine e = affine_load(em);
+                if (t & 1) e.x = fp_mul(e.x, beta);
+                if (d < 0) e.y = fp_neg(e.y);
                 xyzz_madd(acc, e);
             }
-            int d2 = dj[36 + w];
-            if (d2 != 0) {
-                affine e = *reinterpret_cast<const affine*>(&tj[(d2 < 0 ? -d2 : d2) - 1]);
-                e.x = fp_mul(e.x, beta);
-                if (d2 < 0) e.y = fp_neg(e.y);
-                xyzz_madd(acc, e);
-            }
+            d = dn;
+            em = en;
         }
+        for (int i = 0; i < (DW + 3) / 4; i++) dcur[i] = dnext[i];
     }
     return acc;
 }

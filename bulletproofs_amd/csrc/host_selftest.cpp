@@ -122,9 +122,10 @@ void bpt_ec_dbl_n(uint8_t* out, const uint8_t* a, int k) {
 // sum_j k_j * a_j for cnt <= 4 points through the one-lane interleaved routine
 void bpt_ec_mul_glv_multi(uint8_t* out, const uint8_t* a, const uint8_t* k, int cnt) {
     xyzz tab[4 * ECMUL_SLOTS];
-    int8_t dig[4 * ECMUL_DIGB];
+    affine_mem atab[4 * ECMUL_NT];
+    alignas(16) int8_t dig[4 * ECMUL_DIGB];
     xyzz r = ec_mul_glv_multi<4>([&](int j) { return affine_from_be64(a + 64 * j); }, [&](int j) { return fq_from_be_reduce(k + 32 * j); }, cnt,
-                                 tab, dig);
+                                 tab, atab, dig);
     affine_to_be64(out, xyzz_to_affine(r));
 }
 int bpt_ec_decompress(uint8_t* out, const uint8_t* in33) {

@@ -74,8 +74,9 @@ size_t rlc_colsum_chunks(size_t nproofs);
 hipError_t launch_rlc_colsum(int np, size_t nproofs, const fqm* rho, const fqm* scF, const int* bad, fqm* part, uint8_t* out_be, hipStream_t st);
 hipError_t launch_rlc_verdicts(size_t nproofs, const uint8_t* result_be, const int* bad, uint8_t* verdicts, int* all_ok, hipStream_t st);
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
-                          const tdig_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st, int wip = 0,
-                          int nm_tab = 0);
+                          const tdig_t* digF, const fq* varS, xyzz* vartab, xyzz* fixpart, const int* bad, uint8_t* verdicts, hipStream_t st,
+                          int wip = 0, int nm_tab = 0);
+size_t bpv_msm_fixpart_bytes(size_t nproofs);
 // Bulletproofs+ twins (RangeProofWIP::aggregated_verify): proof-point order b_tag, A, L[k], R[k], a_tag, V[m]
 hipError_t launch_wipv_decompress(const uint8_t* proofs, size_t proof_len, const uint8_t* coms_xy, int k, int m, size_t nproofs, affine_mem* pts,
                                   int* bad, hipStream_t st);

@@ -61,7 +61,7 @@ __global__ void k_mb_digits(const uint8_t* __restrict__ scalars_be, size_t total
 __global__ __launch_bounds__(256, 2) void k_mb_msm(size_t njobs, int np, const affine_mem* __restrict__ table, int c, int W,
                                                    const tdig_t* __restrict__ digF, const uint8_t* __restrict__ has_gen,
                                                    const affine_mem* __restrict__ xpts, const uint8_t* __restrict__ xsc_be,
-                                                   const uint32_t* __restrict__ xoff, xyzz* __restrict__ vartab, int8_t* __restrict__ vardig,
+                                                   const uint32_t* __restrict__ xoff, xyzz* __restrict__ vartab, affine_mem* __restrict__ varaff, int8_t* __restrict__ vardig,
                                                    xyzz* __restrict__ out) {
     __shared__ xyzz red[256];
     const int tid = threadIdx.x, lane = tid % MB_TP;
@@ -83,10 +83,11 @@ __global__ __launch_bounds__(256, 2) void k_mb_msm(size_t njobs, int np, const a
         }
         const size_t gl = (size_t)blockIdx.x * 256 + tid;
         xyzz* tab = vartab + gl * ECMUL_SLOTS;
+        affine_mem* atab = varaff + gl * ECMUL_NT;
         int8_t* dig = vardig + gl * ECMUL_DIGB;
         for (uint32_t v = xoff[job] + lane; v < xoff[job + 1]; v += MB_TP) {
             xyzz t = ec_mul_glv_multi<1>([&](int) { return affine_load(xpts[v]); }, [&](int) { return fq_from_be_reduce(xsc_be + 32 * (size_t)v); }, 1,
-                                         tab, dig);
+                                         tab, atab, dig);
             xyzz_add(acc, t);
         }
     }
@@ -111,13 +112,15 @@ hipError_t launch_mb_digits(const uint8_t* scalars_be, size_t total, int c, int 
 }
 size_t mb_vartab_bytes(size_t njobs) {
     size_t blocks = (njobs + (256 / MB_TP) - 1) / (256 / MB_TP);
-    return blocks * 256 * (ECMUL_SLOTS * sizeof(xyzz) + ECMUL_DIGB);
+    return blocks * 256 * (ECMUL_SLOTS * sizeof(xyzz) + ECMUL_NT * sizeof(affine_mem) + ECMUL_DIGB);
 }
 hipError_t launch_mb_msm(size_t njobs, int np, const affine_mem* table, int c, int W, const tdig_t* digF, const uint8_t* has_gen,
                          const affine_mem* xpts, const uint8_t* xsc_be, const uint32_t* xoff, xyzz* vartab, xyzz* out, hipStream_t st) {
     unsigned blocks = (unsigned)((njobs + (256 / MB_TP) - 1) / (256 / MB_TP));
-    int8_t* vardig = reinterpret_cast<int8_t*>(vartab + (size_t)blocks * 256 * ECMUL_SLOTS);
-    hipLaunchKernelGGL(k_mb_msm, dim3(blocks), dim3(256), 0, st, njobs, np, table, c, W, digF, has_gen, xpts, xsc_be, xoff, vartab, vardig, out);
+    affine_mem* varaff = reinterpret_cast<affine_mem*>(vartab + (size_t)blocks * 256 * ECMUL_SLOTS);
+    int8_t* vardig = reinterpret_cast<int8_t*>(varaff + (size_t)blocks * 256 * ECMUL_NT);
+    hipLaunchKernelGGL(k_mb_msm, dim3(blocks), dim3(256), 0, st, njobs, np, table, c, W, digF, has_gen, xpts, xsc_be, xoff, vartab, varaff, vardig,
+                       out);
     return hipGetLastError();
 }
 

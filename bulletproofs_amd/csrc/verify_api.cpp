@@ -252,13 +252,14 @@ struct VerifyWs {
     fq* chal;          // challenges, then the per-proof constants (cst)
     xyzz* fixres;      // y*G, x_u*G (projective), then their affine forms
     xyzz* vartab;      // lane-private window tables of k_bpv_msm
+    xyzz* fixpart;     // per-proof sum of the fixed-generator terms (k_bpv_fix -> k_bpv_msm)
 };
 struct VerifySizes {
-    size_t pts, bad, dig, var, chal, fixres, vartab;
+    size_t pts, bad, dig, var, chal, fixres, vartab, fixpart;
     int tp;
     size_t total() const {  // as laid out by carve(): every slice starts on a 256-byte boundary
         size_t t = 0;
-        for (size_t b : {pts, bad, dig, var, chal, fixres, vartab}) t += (b + 255) / 256 * 256;
+        for (size_t b : {pts, bad, dig, var, chal, fixres, vartab, fixpart}) t += (b + 255) / 256 * 256;
         return t;
     }
 };
@@ -283,6 +284,7 @@ static VerifySizes verify_ws_sizes(const bp_ctx* ctx, const bp_gens* gens, int n
     }
     z.tp = tp;
     z.vartab = bpv_msm_vartab_bytes(tp, nproofs);
+    z.fixpart = bpv_msm_fixpart_bytes(nproofs);
     return z;
 }
 
@@ -315,7 +317,9 @@ static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bi
     if ((rc = b_s.reserve(z.chal)) != BP_OK) return rc;
     if ((rc = ctx->fixres.reserve(z.fixres)) != BP_OK) return rc;
     if ((rc = ctx->vartab.reserve(z.vartab)) != BP_OK) return rc;
-    VerifyWs ws{(affine_mem*)b_pts.p, (int*)b_bad.p, (tdig_t*)b_dig.p, (fq*)b_var.p, (fq*)b_s.p, (xyzz*)ctx->fixres.p, (xyzz*)ctx->vartab.p};
+    if ((rc = ctx->fixpart.reserve(z.fixpart)) != BP_OK) return rc;
+    VerifyWs ws{(affine_mem*)b_pts.p, (int*)b_bad.p, (tdig_t*)b_dig.p, (fq*)b_var.p, (fq*)b_s.p, (xyzz*)ctx->fixres.p, (xyzz*)ctx->vartab.p,
+                (xyzz*)ctx->fixpart.p};
     return verify_batch_launch(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, wip, ws, z.tp);
 }
 
@@ -349,7 +353,7 @@ static int verify_batch_launch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int
                                           gens->W, ws.dig, nullptr, ws.var, d_chal, d_cst, d_fixres, d_fixaff, ws.bad, st, gens->ibase, (int)gens->nm),
                "bpv_scalars");
     prof_mark(ctx, 2);
-    HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, ws.pts, gens->d_table, gens->c, gens->W, ws.dig, ws.var, ws.vartab, ws.bad,
+    HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, ws.pts, gens->d_table, gens->c, gens->W, ws.dig, ws.var, ws.vartab, ws.fixpart, ws.bad,
                           (uint8_t*)d_verdicts, st, wip, (int)gens->nm),
            "bpv_msm");
     prof_mark(ctx, 3);
@@ -427,6 +431,7 @@ int bp_rangeproof_verify_batch_device_noalloc(bp_ctx* ctx, const bp_gens* gens, 
     ws.chal = (fq*)carve(z.chal);
     ws.fixres = (xyzz*)carve(z.fixres);
     ws.vartab = (xyzz*)carve(z.vartab);
+    ws.fixpart = (xyzz*)carve(z.fixpart);
     // The array keeps the previous call's contents.  Only `bad` must start at zero (verify_batch_launch clears it on the
     // stream); every other slice is written by the kernels of this call before it is read.
     return verify_batch_launch(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, 0, ws, z.tp);

@@ -87,27 +87,25 @@ __global__ void k_wipv_decompress(const uint8_t* __restrict__ proofs, size_t pro
 }
 
 // ------------------------------------------------------------------------------------------------
-#ifndef BPV_MSM_WAVES
-#define BPV_MSM_WAVES 2
+// ------------------------------------------------------------------------------------------------
+// Fixed-generator half of the verification MSM (the 2nm+2 terms over g_vec, h_vec, G, H; range_proof.rs:742-774): table
+// gathers + mixed additions only, no doublings.  A kernel of its own because the loop needs ~120 VGPRs, so it runs at 4
+// waves per SIMD where the proof-specific half (233 VGPRs) runs at 2, and because the next table entry can be fetched
+// while the current one is being added: the 64-byte gather from a table of tens of GiB is an HBM round trip, hidden
+// behind a 3.4 us mixed addition instead of exposed in front of it.  TP lanes per proof, LDS tree, one XYZZ partial
+// per proof in `fixpart`, which k_bpv_msm adds to its own sum.
+#ifndef BPV_FIX_WAVES
+#define BPV_FIX_WAVES 3
 #endif
-
-// TP lanes per proof, PPL proof-specific points per lane and pass (one shared doubling chain per
-// lane: the fewer lanes a proof has, the fewer chains it pays for); 256-thread workgroups.
-template <int TP, int PPL>
-__global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int m, int k, size_t nproofs, const affine_mem* __restrict__ pts,
-                                                 const affine_mem* __restrict__ table, int c, int W, const tdig_t* __restrict__ digF,
-                                                 const fq* __restrict__ varS, xyzz* __restrict__ vartab, int8_t* __restrict__ vardig,
-                                                 const int* __restrict__ bad, uint8_t* __restrict__ verdicts, int wip, int shiftW) {
+template <int TP>
+__global__ __launch_bounds__(256, BPV_FIX_WAVES) void k_bpv_fix(int nm, size_t nproofs, const affine_mem* __restrict__ table, int c, int W,
+                                                    const tdig_t* __restrict__ digF, const int* __restrict__ bad, int shiftW,
+                                                    xyzz* __restrict__ fixpart) {
     __shared__ xyzz red[256];
     const int tid = threadIdx.x;
     const int lane = tid % TP;
     const size_t pr = (size_t)blockIdx.x * (256 / TP) + tid / TP;
-    const bool active = pr < nproofs && !(pr < nproofs && bad[pr]);
-    const int nm = n_bits * m;
-    // Bulletproofs: pts = A S T1 T2 L[k] R[k] V[m], 3+2k+m variable terms, compared with A.
-    // Bulletproofs+ (wip): pts = b_tag A L[k] R[k] a_tag V[m], variable terms pts[1..], compared with b_tag.
-    const int NPT = (wip ? 3 : 4) + 2 * k + m;
-    const int NV = (wip ? 2 : 3) + 2 * k + m;
+    const bool active = pr < nproofs && !bad[pr];
     const int NB = 1 << (c - 1);
     xyzz acc = xyzz_inf();
     if (active) {
@@ -116,19 +114,76 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
         // shiftW != 0: the proof uses the first nm of the table's nm_tab generators per vector (a batch mixing aggregation
         // sizes over one bp_gens): h_vec's rows start (nm_tab - nm) rows later, G and H twice that
         const int hW = nm * W, gW = 2 * nm * W;
+        auto fetch = [&](int idx, int& d, affine_mem& e) {
+            d = 0;
+            if (idx < nfw) {
+                d = dg[idx];
+                if (d != 0) {
+                    const int row = idx + (idx >= hW ? shiftW : 0) + (idx >= gW ? shiftW : 0);
+                    e = table[(size_t)row * NB + ((d < 0 ? -d : d) - 1)];
+                }
+            }
+        };
+        int dcur, dnext;
+        affine_mem cur, next;
+        fetch(lane, dcur, cur);
         for (int idx = lane; idx < nfw; idx += TP) {
-            int d = dg[idx];
-            if (d != 0) {
-                const int row = idx + (idx >= hW ? shiftW : 0) + (idx >= gW ? shiftW : 0);
-                affine e = affine_load(table[(size_t)row * NB + ((d < 0 ? -d : d) - 1)]);
-                if (d < 0) e.y = fp_neg(e.y);
+            fetch(idx + TP, dnext, next);  // in flight during the addition below
+            if (dcur != 0) {
+                affine e = affine_load(cur);
+                if (dcur < 0) e.y = fp_neg(e.y);
                 xyzz_madd(acc, e);
             }
+            cur = next;
+            dcur = dnext;
         }
+    }
+    if (TP > 1) {
+        red[tid] = acc;
+        __syncthreads();
+        for (int off = TP / 2; off >= 1; off >>= 1) {
+            if (lane < off) {
+                xyzz v = red[tid];
+                xyzz o = red[tid + off];
+                xyzz_add(v, o);
+                red[tid] = v;
+            }
+            __syncthreads();
+        }
+        acc = red[tid];
+    }
+    if (lane == 0 && pr < nproofs) fixpart[pr] = acc;
+}
+
+#ifndef BPV_MSM_WAVES
+#define BPV_MSM_WAVES 2
+#endif
+
+// TP lanes per proof, PPL proof-specific points per lane and pass (one shared doubling chain per
+// lane: the fewer lanes a proof has, the fewer chains it pays for); 256-thread workgroups.
+template <int TP, int PPL>
+__global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int m, int k, size_t nproofs, const affine_mem* __restrict__ pts,
+                                                 const xyzz* __restrict__ fixpart,
+                                                 const fq* __restrict__ varS, xyzz* __restrict__ vartab, affine_mem* __restrict__ varaff,
+                                                 int8_t* __restrict__ vardig, const int* __restrict__ bad, uint8_t* __restrict__ verdicts,
+                                                 int wip) {
+    __shared__ xyzz red[256];
+    const int tid = threadIdx.x;
+    const int lane = tid % TP;
+    const size_t pr = (size_t)blockIdx.x * (256 / TP) + tid / TP;
+    const bool active = pr < nproofs && !(pr < nproofs && bad[pr]);
+    // Bulletproofs: pts = A S T1 T2 L[k] R[k] V[m], 3+2k+m variable terms, compared with A.
+    // Bulletproofs+ (wip): pts = b_tag A L[k] R[k] a_tag V[m], variable terms pts[1..], compared with b_tag.
+    const int NPT = (wip ? 3 : 4) + 2 * k + m;
+    const int NV = (wip ? 2 : 3) + 2 * k + m;
+    xyzz acc = xyzz_inf();
+    if (active) {
+        if (lane == 0) acc = fixpart[pr];  // the fixed-generator half, summed by k_bpv_fix
         const affine_mem* P = pts + pr * NPT;
         const fq* vs = varS + pr * (size_t)NV;
         const size_t gl = (size_t)blockIdx.x * 256 + tid;
         xyzz* tab = vartab + gl * (PPL * ECMUL_SLOTS);
+        affine_mem* atab = varaff + gl * (PPL * ECMUL_NT);
         int8_t* dig = vardig + gl * (PPL * ECMUL_DIGB);
         for (int v0 = lane; v0 < NV; v0 += TP * PPL) {
             int cnt = (NV - v0 + TP - 1) / TP;
@@ -140,7 +195,7 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
                 return affine_load(P[pi]);
             };
             auto loadK = [&](int j) { return vs[v0 + TP * j]; };
-            xyzz t = ec_mul_glv_multi<PPL>(loadP, loadK, cnt, tab, dig);
+            xyzz t = ec_mul_glv_multi<PPL>(loadP, loadK, cnt, tab, atab, dig);
             xyzz_add(acc, t);
         }
     }
@@ -188,16 +243,44 @@ hipError_t launch_wipv_decompress(const uint8_t* proofs, size_t proof_len, const
 static int bpv_ppl(int tp) { return tp == 2 ? 8 : (tp == 4 ? 4 : (tp == 8 ? 2 : 1)); }
 size_t bpv_msm_vartab_bytes(int tp, size_t nproofs) {
     size_t blocks = (nproofs + (256 / tp) - 1) / (256 / tp);
-    return blocks * 256 * bpv_ppl(tp) * (ECMUL_SLOTS * sizeof(xyzz) + ECMUL_DIGB);
+    return blocks * 256 * bpv_ppl(tp) * (ECMUL_SLOTS * sizeof(xyzz) + ECMUL_NT * sizeof(affine_mem) + ECMUL_DIGB);
+}
+size_t bpv_msm_fixpart_bytes(size_t nproofs) { return nproofs * sizeof(xyzz); }
+// lanes per proof of the fixed-generator kernel: enough for 4 waves on every SIMD (262144 lanes) when the batch allows
+static int bpv_fix_lanes(int tp, size_t nproofs, int nm) {
+    int tf = tp < 4 ? 4 : tp;
+    while (tf < 64 && nproofs * (size_t)tf < 262144) tf *= 2;
+    while (tf > 2 && tf > 2 * nm + 2) tf /= 2;
+    return tf;
 }
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
-                          const tdig_t* digF, const fq* varS, xyzz* vartab, const int* bad, uint8_t* verdicts, hipStream_t st, int wip, int nm_tab) {
-    const int shiftW = nm_tab > n_bits * m ? (nm_tab - n_bits * m) * W : 0;
+                          const tdig_t* digF, const fq* varS, xyzz* vartab, xyzz* fixpart, const int* bad, uint8_t* verdicts, hipStream_t st,
+                          int wip, int nm_tab) {
+    const int nm = n_bits * m;
+    const int shiftW = nm_tab > nm ? (nm_tab - nm) * W : 0;
+    const int tf = bpv_fix_lanes(tp, nproofs, nm);
+    unsigned fblocks = (unsigned)((nproofs + (256 / tf) - 1) / (256 / tf));
+#define BPV_FIX(TP) hipLaunchKernelGGL((k_bpv_fix<TP>), dim3(fblocks), dim3(256), 0, st, nm, nproofs, table, c, W, digF, bad, shiftW, fixpart)
+    if (tf == 4)
+        BPV_FIX(4);
+    else if (tf == 8)
+        BPV_FIX(8);
+    else if (tf == 16)
+        BPV_FIX(16);
+    else if (tf == 32)
+        BPV_FIX(32);
+    else if (tf == 64)
+        BPV_FIX(64);
+    else
+        BPV_FIX(2);
+#undef BPV_FIX
     unsigned blocks = (unsigned)((nproofs + (256 / tp) - 1) / (256 / tp));
-    int8_t* vardig = reinterpret_cast<int8_t*>(vartab + (size_t)blocks * 256 * bpv_ppl(tp) * ECMUL_SLOTS);
+    // vartab = [XYZZ construction slots | finished 64-byte tables | digits], each per lane
+    affine_mem* varaff = reinterpret_cast<affine_mem*>(vartab + (size_t)blocks * 256 * bpv_ppl(tp) * ECMUL_SLOTS);
+    int8_t* vardig = reinterpret_cast<int8_t*>(varaff + (size_t)blocks * 256 * bpv_ppl(tp) * ECMUL_NT);
 #define BPV_LAUNCH(TP, PPL)                                                                                                                  \
-    hipLaunchKernelGGL((k_bpv_msm<TP, PPL>), dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, table, c, W, digF, varS, vartab, vardig, \
-                       bad, verdicts, wip, shiftW)
+    hipLaunchKernelGGL((k_bpv_msm<TP, PPL>), dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, fixpart, varS, vartab, varaff, vardig, bad, \
+                       verdicts, wip)
     if (tp == 2)
         BPV_LAUNCH(2, 8);
     else if (tp == 4)
