@@ -115,7 +115,7 @@ SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
     // chunk of points per histogram workgroup: ~512 workgroups in flight, 4096..65536 points each
     size_t ch = 4096;
     while (ch < 65536 && ((n2 + ch - 1) / ch) * (size_t)pl.W > 512) ch *= 2;
-    if (const char* e = getenv("BP_MSM_CH")) ch = (size_t)atol(e) >= 1024 ? (size_t)atol(e) : ch;
+    if (const char* e = getenv("BP_MSM_CH")) ch = (size_t)atol(e) >= 1024 ? ((size_t)atol(e) + 7) & ~(size_t)7 : ch;  // read 8 digits at a time
     pl.CH = (int)ch;
     pl.nchunks = (int)((n2 + ch - 1) / ch);
     if (pl.nchunks < 1) pl.nchunks = 1;
@@ -136,8 +136,9 @@ SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
 }
 
 // Window groups of the pipelined sorted path (top-down).  Measured at 2^20 / 2^22 points (gpurun_out sweeps,
-// DESIGN.md section 5): two groups are the optimum - an accumulation launch needs >= 4 windows (4 waves per SIMD)
-// to run at full rate, so finer pipelines lose more in the accumulation than the shorter exposed tail returns.
+// DESIGN.md section 5): an accumulation launch of >= 3 windows fills the SIMDs; the LAST group is one window, so that the
+// exposed tail is one window's bucket reduction and a single addition (its Horner step is done by k_srt_dbl while the
+// window still accumulates) - 5,3,1 at W = 9: 2.38-2.51 ms against 2.53-2.65 for 5,4 and 2.9 for 4,2,2,1.
 // BP_MSM_GROUPS="3,3,2,1" overrides (tuning).
 static int plan_window_groups(int W, int* gsz) {
     int ng = 0;
@@ -157,9 +158,15 @@ static int plan_window_groups(int W, int* gsz) {
         if (ng > 0) return ng;
     }
     if (W < 4) return 0;
-    gsz[0] = W - W / 2;
-    gsz[1] = W / 2;
-    return 2;
+    if (W < 6) {
+        gsz[0] = W - W / 2;
+        gsz[1] = W / 2;
+        return 2;
+    }
+    gsz[0] = ((W - 1) * 5 + 7) / 8;
+    gsz[1] = W - 1 - gsz[0];
+    gsz[2] = 1;
+    return 3;
 }
 
 #define HIPCHK(expr, where)              \
@@ -241,6 +248,7 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
             ctx->srt_streams = ss;
             HIPCHK(hipStreamCreateWithFlags(&ss->st2, hipStreamNonBlocking), "hipStreamCreate");
             HIPCHK(hipStreamCreateWithFlags(&ss->st3, hipStreamNonBlocking), "hipStreamCreate");
+            ss->st4 = ss->st2;  // a stream of its own shared st3's hardware queue (4 per process) and serialised the two
             for (int g = 0; g < SortedStreams::kMaxGroups; g++) {
                 HIPCHK(hipEventCreateWithFlags(&ss->ev_acc[g], hipEventDisableTiming), "hipEventCreate");
                 HIPCHK(hipEventCreateWithFlags(&ss->ev_red[g], hipEventDisableTiming), "hipEventCreate");
@@ -249,8 +257,12 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
             HIPCHK(hipEventCreateWithFlags(&ss->ev_join, hipEventDisableTiming), "hipEventCreate");
             HIPCHK(hipEventCreateWithFlags(&ss->ev_fork, hipEventDisableTiming), "hipEventCreate");
         }
-        HIPCHK(launch_msm_sorted(d_points, lam, n, (const int16_t*)ctx->digits.p, n2, pl, b, (xyzz*)ctx->wsum.p, st, ctx->srt_streams, gsz, ng, W_out),
+        pl.ncu = ctx->ncu;
+        int c_eff = pl.c;
+        HIPCHK(launch_msm_sorted(d_points, lam, n, (const int16_t*)ctx->digits.p, n2, pl, b, (xyzz*)ctx->wsum.p, st, ctx->srt_streams, gsz, ng, W_out,
+                                 &c_eff),
                "sorted msm");
+        *c_out = c_eff;
     }
     return BP_OK;
 }
@@ -340,6 +352,7 @@ int bp_ctx_create(int device, bp_ctx** out) {
     if (int rc = noalloc_init_device(device)) return rc;
     bp_ctx* ctx = new bp_ctx();
     ctx->device = device;
+    if (hipDeviceGetAttribute(&ctx->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ctx->ncu = 0;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("hipStreamCreate", e);

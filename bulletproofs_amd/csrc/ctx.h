@@ -38,6 +38,7 @@ struct bp_ctx {
     bp::SortedStreams* srt_streams = nullptr;
     int* d_err = nullptr;
     int forced_c = 0;
+    int ncu = 0;  // compute units of the device (window-group launches are sized per CU)
     int msm_path = 0;  // 0 auto, 1 LDS slice path, 2 sorted path (bp_msm_set_path)
     int msm_pipeline = 0;  // 0 = window groups on side streams (lowest latency of one call), 1 = one group (bp_msm_set_pipeline)
     int verify_lanes = 0;

@@ -33,6 +33,7 @@ hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine_mem* i
 // msm_sorted.hip: large-N path (global counting sort by bucket, balanced segment accumulation)
 struct SortedPlan {
     int c, W, NB, CH, nchunks, L, nseg, lo_bits;
+    int ncu;  // compute units of the device (0 = unknown)
     size_t npad;
 };
 struct SortedBufs {
@@ -40,14 +41,15 @@ struct SortedBufs {
     uint2* ent;
     xyzz *Bk, *Pseg, *RC;
 };
-// second/third stream + events of the grouped pipeline (see launch_msm_sorted)
+// side streams + events of the grouped pipeline (see launch_msm_sorted): st2 sorts, st3 bucket reductions, st4 Horner chain
 struct SortedStreams {
     static const int kMaxGroups = 8;
-    hipStream_t st2, st3;
+    hipStream_t st2, st3, st4;
     hipEvent_t ev_acc[kMaxGroups], ev_red[kMaxGroups], ev_sorted[kMaxGroups], ev_join, ev_fork;
 };
 hipError_t launch_msm_sorted(const affine_mem* pts, const affine_mem* lam, size_t n1, const int16_t* digits, size_t n2, const SortedPlan& pl,
-                             const SortedBufs& b, xyzz* wsum, hipStream_t st, const SortedStreams* ss, const int* gsz, int ng, int* W_eff);
+                             const SortedBufs& b, xyzz* wsum, hipStream_t st, const SortedStreams* ss, const int* gsz, int ng, int* W_eff,
+                             int* c_eff);
 
 // gens_kernels.hip
 hipError_t launch_gens_bases(const affine_mem* pts, int np, int c, int W, xyzz* bases, hipStream_t st);

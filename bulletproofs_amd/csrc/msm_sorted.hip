@@ -29,7 +29,16 @@
 
 namespace bp {
 
-#define SRT_T 1024
+// 512-lane workgroups (two waves per SIMD, <= 64 VGPRs): a sort workgroup of a later window group fits beside the two
+// accumulation waves per SIMD of the group before it (launch_msm_sorted)
+#define SRT_T 512
+
+// Digits are read eight at a time (one 16-byte load per lane and step: a chunk of 65536 digits is 8 dependent
+// load -> LDS-atomic steps per lane instead of 64); the columns [n2, npad) hold zero digits, so whole chunks are read.
+__device__ __forceinline__ int srt_digit(const uint4& q, int h) {
+    const uint32_t wd = (h >> 1) == 0 ? q.x : (h >> 1) == 1 ? q.y : (h >> 1) == 2 ? q.z : q.w;
+    return (int)(int16_t)((h & 1) ? (wd >> 16) : (wd & 0xffffu));
+}
 
 __global__ __launch_bounds__(SRT_T) void k_srt_hist(const int16_t* __restrict__ digits, size_t n2, size_t npad, int CH, int NB, int w0,
                                                     uint32_t* __restrict__ cnt) {
@@ -38,11 +47,16 @@ __global__ __launch_bounds__(SRT_T) void k_srt_hist(const int16_t* __restrict__ 
     for (int b = tid; b < NB; b += SRT_T) srt_h[b] = 0;
     __syncthreads();
     const size_t base = (size_t)chunk * CH;
-    const int len = base >= n2 ? 0 : (int)((n2 - base) < (size_t)CH ? (n2 - base) : (size_t)CH);
-    const int16_t* dg = digits + (size_t)w * npad + base;
-    for (int i = tid; i < len; i += SRT_T) {
-        int d = dg[i];
-        if (d != 0) atomicAdd(&srt_h[(d < 0 ? -d : d) - 1], 1u);
+    const uint4* dg = reinterpret_cast<const uint4*>(digits + (size_t)w * npad + base);
+    if (base < n2) {
+        for (int i = tid; i < CH / 8; i += SRT_T) {
+            const uint4 q = dg[i];
+#pragma unroll
+            for (int h = 0; h < 8; h++) {
+                const int d = srt_digit(q, h);
+                if (d != 0) atomicAdd(&srt_h[(d < 0 ? -d : d) - 1], 1u);
+            }
+        }
     }
     __syncthreads();
     uint32_t* o = cnt + ((size_t)w * nchunks + chunk) * NB;
@@ -102,23 +116,35 @@ __global__ __launch_bounds__(SRT_T) void k_srt_scatter(const int16_t* __restrict
     for (int b = tid; b < NB; b += SRT_T) srt_h[b] = bs[b] + o[b];
     __syncthreads();
     const size_t base = (size_t)chunk * CH;
-    const int len = base >= n2 ? 0 : (int)((n2 - base) < (size_t)CH ? (n2 - base) : (size_t)CH);
-    const int16_t* dg = digits + (size_t)w * npad + base;
+    if (base >= n2) return;
+    const uint4* dg = reinterpret_cast<const uint4*>(digits + (size_t)w * npad + base);
     uint2* E = ent + (size_t)w * npad;
-    for (int i = tid; i < len; i += SRT_T) {
-        int d = dg[i];
-        if (d != 0) {
-            int b = (d < 0 ? -d : d) - 1;
-            uint32_t pos = atomicAdd(&srt_h[b], 1u);
-            E[pos] = make_uint2((uint32_t)(base + i) | (d < 0 ? 0x80000000u : 0u), (uint32_t)b);  // one 8-byte store per entry
+    for (int i = tid; i < CH / 8; i += SRT_T) {
+        const uint4 q = dg[i];
+#pragma unroll
+        for (int h = 0; h < 8; h++) {
+            const int d = srt_digit(q, h);
+            if (d != 0) {
+                const int b = (d < 0 ? -d : d) - 1;
+                const uint32_t pos = atomicAdd(&srt_h[b], 1u);
+                E[pos] = make_uint2((uint32_t)(base + 8 * i + h) | (d < 0 ? 0x80000000u : 0u), (uint32_t)b);  // one 8-byte store per entry
+            }
         }
     }
 }
 
+// The loop is software-pipelined so that a wave does not need its neighbours to hide the gathers (a group of few
+// windows runs at one or two waves per SIMD): the point of entry j + 1 is requested before the addition of entry j
+// starts.  Entries are read one 64-byte line (8 entries, four 16-byte loads) at a time into an entry-major LDS slot
+// (conflict-free 8-byte reads); j0 is a multiple of 8 and the window's array 64-byte aligned.  With one 8-byte global
+// load per iteration the line was fetched again for every entry (the point gathers sweep the caches in between):
+// TCC_EA read requests 27.5 M per launch against 10.6 M algorithmic.
 __global__ __launch_bounds__(256, 2) void k_srt_acc(const affine_mem* __restrict__ pts, const affine_mem* __restrict__ lam, size_t n1,
                                                     const uint2* __restrict__ ent, const uint32_t* __restrict__ bstart, size_t npad, int NB, int L, int nseg,
-                                                    int w0, int nw, xyzz* __restrict__ Bk, xyzz* __restrict__ Pseg) {
-    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+                                                    int pstride, int w0, int nw, xyzz* __restrict__ Bk, xyzz* __restrict__ Pseg) {
+    __shared__ uint2 line[8][256];
+    const int tid = threadIdx.x;
+    const size_t g = (size_t)blockIdx.x * 256 + tid;
     const int w = w0 + (int)(g / nseg), t = (int)(g % nseg);
     if (w >= w0 + nw) return;
     const uint32_t Nw = bstart[(size_t)w * (NB + 1) + NB];
@@ -127,39 +153,57 @@ __global__ __launch_bounds__(256, 2) void k_srt_acc(const affine_mem* __restrict
     const uint32_t j1 = (j0 + L < Nw) ? j0 + L : Nw;
     const uint2* E = ent + (size_t)w * npad;
     xyzz acc = xyzz_inf();
-    int cur = (int)E[j0].y;
     bool atstart = true;
-    // Entries are read one 64-byte line (8 entries, four 16-byte loads) at a time; j0 is a multiple of 8 and the window's
-    // array 64-byte aligned.  With one 8-byte load per iteration the line was fetched again for every entry (the point
-    // gathers sweep the caches in between): TCC_EA read requests 27.5 M per launch against 10.6 M algorithmic.
-    for (uint32_t j = j0; j < j1; j += 8) {
-        uint4 q[4];
+    // line of entries j0 .. j0 + 7 (entries past Nw are never used)
+    {
+        const uint4* q = reinterpret_cast<const uint4*>(E + j0);
 #pragma unroll
-        for (int h = 0; h < 4; h++) q[h] = *reinterpret_cast<const uint4*>(E + j + 2 * h);
-        const int cnt = (j1 - j) < 8u ? (int)(j1 - j) : 8;
-#pragma unroll
-        for (int h = 0; h < 8; h++) {
-            if (h < cnt) {
-                const uint32_t e = (h & 1) ? q[h >> 1].z : q[h >> 1].x;
-                const int b = (int)((h & 1) ? q[h >> 1].w : q[h >> 1].y);
-                if (b != cur) {
-                    if (atstart)
-                        Pseg[(size_t)w * nseg + t] = acc;
-                    else
-                        Bk[(size_t)w * NB + cur] = acc;
-                    acc = xyzz_inf();
-                    cur = b;
-                    atstart = false;
-                }
-                size_t v = e & 0x7fffffffu;
-                affine p = affine_load(v < n1 ? pts[v] : lam[v - n1]);
-                if (e >> 31) p.y = fp_neg(p.y);
-                xyzz_madd(acc, p);
-            }
+        for (int h = 0; h < 4; h++) {
+            const uint4 v = q[h];
+            line[2 * h][tid] = make_uint2(v.x, v.y);
+            line[2 * h + 1][tid] = make_uint2(v.z, v.w);
         }
     }
+    uint2 en = line[0][tid];
+    int cur = (int)en.y;
+    affine_mem nxt;
+    {
+        const size_t v = en.x & 0x7fffffffu;
+        nxt = v < n1 ? pts[v] : lam[v - n1];
+    }
+    for (uint32_t j = j0; j < j1; j++) {
+        const uint2 ec = en;
+        affine p = affine_load(nxt);
+        if (j + 1 < j1) {
+            const uint32_t h = (j + 1 - j0) & 7u;
+            if (h == 0) {
+                const uint4* q = reinterpret_cast<const uint4*>(E + j + 1);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint4 v = q[k];
+                    line[2 * k][tid] = make_uint2(v.x, v.y);
+                    line[2 * k + 1][tid] = make_uint2(v.z, v.w);
+                }
+            }
+            en = line[h][tid];
+            const size_t v = en.x & 0x7fffffffu;
+            nxt = v < n1 ? pts[v] : lam[v - n1];
+        }
+        const int b = (int)ec.y;
+        if (b != cur) {
+            if (atstart)
+                Pseg[(size_t)w * pstride + t] = acc;
+            else
+                Bk[(size_t)w * NB + cur] = acc;
+            acc = xyzz_inf();
+            cur = b;
+            atstart = false;
+        }
+        if (ec.x >> 31) p.y = fp_neg(p.y);
+        xyzz_madd(acc, p);
+    }
     if (atstart)
-        Pseg[(size_t)w * nseg + t] = acc;
+        Pseg[(size_t)w * pstride + t] = acc;
     else
         Bk[(size_t)w * NB + cur] = acc;
 }
@@ -222,9 +266,10 @@ __global__ __launch_bounds__(256) void k_srt_window(const uint32_t* __restrict__
     if (tid == 0) wsum[w] = red[0];
 }
 
-// wsum[w_lo] = sum_{w_lo <= w < w_hi} 2^(c (w - w_lo)) wsum[w]: Horner over the top windows, one lane,
-// so that this serial chain can run on a second stream while the low windows are still accumulating.
-__global__ __launch_bounds__(64) void k_srt_horner_part(xyzz* __restrict__ wsum, int w_lo, int w_hi, int c) {
+// wsum[w_lo] = sum_{w_lo <= w < w_hi} 2^(c (w - w_lo)) wsum[w]  (+ wsum[vidx] when vidx >= 0: the combination of the
+// window groups above, already multiplied by 2^(c (w_hi - w_lo)) by k_srt_dbl): Horner over one group's windows, one
+// lane, so that this serial chain runs on a side stream while the lower windows are still accumulating.
+__global__ __launch_bounds__(64) void k_srt_horner_part(xyzz* __restrict__ wsum, int w_lo, int w_hi, int c, int vidx) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     __builtin_amdgcn_s_setprio(3);
     xyzz acc = wsum[w_hi - 1];
@@ -233,7 +278,18 @@ __global__ __launch_bounds__(64) void k_srt_horner_part(xyzz* __restrict__ wsum,
         xyzz o = wsum[w];
         xyzz_add(acc, o);
     }
+    if (vidx >= 0) {
+        xyzz o = wsum[vidx];
+        xyzz_add(acc, o);
+    }
     wsum[w_lo] = acc;
+}
+// wsum[idx] *= 2^k: the doublings the finished groups' combination needs before the next group's windows can be added
+// do not wait for that group's bucket reduction
+__global__ __launch_bounds__(64) void k_srt_dbl(xyzz* __restrict__ wsum, int idx, int k) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __builtin_amdgcn_s_setprio(3);
+    wsum[idx] = xyzz_dbl_n(wsum[idx], k);
 }
 
 // Row and column sums straight from k_srt_acc's outputs (no per-bucket finalize pass): the sum over a set of
@@ -244,7 +300,7 @@ __global__ __launch_bounds__(64) void k_srt_horner_part(xyzz* __restrict__ wsum,
 // with many segments (the short top window, skewed scalars) are summed by the whole workgroup afterwards.
 // Depth: ~2-3 additions per lane + an 8-level LDS tree, whatever the bucket sizes are.
 __global__ __launch_bounds__(256) void k_srt_rowcol2(const uint32_t* __restrict__ bstart, const xyzz* __restrict__ Bk,
-                                                        const xyzz* __restrict__ Pseg, int NB, int L, int nseg, int lo_bits, int w0,
+                                                        const xyzz* __restrict__ Pseg, int NB, int L, int pstride, int lo_bits, int w0,
                                                         xyzz* __restrict__ RC) {
     __shared__ xyzz red[256];
     __builtin_amdgcn_s_setprio(3);  // latency-bound: issue ahead of the co-resident accumulation waves
@@ -258,7 +314,7 @@ __global__ __launch_bounds__(256) void k_srt_rowcol2(const uint32_t* __restrict_
     const int LO = 1 << lo_bits, HI = NBe >> lo_bits, nout = LO + HI;
     if (o >= nout) return;
     const xyzz* B = Bk + (size_t)w * NB;
-    const xyzz* P = Pseg + (size_t)w * nseg;
+    const xyzz* P = Pseg + (size_t)w * pstride;
     const uint32_t uL = (uint32_t)L;
     xyzz acc = xyzz_inf();
     if (tid == 0) nbig = 0;
@@ -340,76 +396,96 @@ static void srt_sort_windows(const int16_t* digits, size_t n2, const SortedPlan&
     hipLaunchKernelGGL(k_srt_bstart, dim3((unsigned)nw), dim3(SRT_T), 0, st, b.bstart, NB, w0);
     hipLaunchKernelGGL(k_srt_scatter, gcw, dim3(SRT_T), lds, st, digits, n2, pl.npad, pl.CH, NB, w0, b.cnt, b.bstart, b.ent);
 }
-// bucket accumulation of the windows [w0, w0 + nw) on stream st
-static void srt_acc_windows(const affine_mem* pts, const affine_mem* lam, size_t n1, const SortedPlan& pl, const SortedBufs& b, int w0, int nw,
-                            hipStream_t st) {
-    size_t nthr = (size_t)nw * pl.nseg;
-    hipLaunchKernelGGL(k_srt_acc, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, pts, lam, n1, b.ent, b.bstart, pl.npad, pl.NB, pl.L,
+// bucket accumulation of the windows [w0, w0 + nw) on stream st, segments of L entries (nseg per window)
+static void srt_acc_windows(const affine_mem* pts, const affine_mem* lam, size_t n1, const SortedPlan& pl, const SortedBufs& b, int w0, int nw, int L,
+                            int nseg, hipStream_t st) {
+    size_t nthr = (size_t)nw * nseg;
+    hipLaunchKernelGGL(k_srt_acc, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, pts, lam, n1, b.ent, b.bstart, pl.npad, pl.NB, L, nseg,
                        pl.nseg, w0, nw, b.Bk, b.Pseg);
 }
 // bucket reduction of the windows [w0, w0 + nw): wsum[w] = sum_b (b+1) bucket_w[b]
-static hipError_t srt_reduce_windows(const SortedPlan& pl, const SortedBufs& b, int w0, int nw, xyzz* wsum, hipStream_t st) {
+static hipError_t srt_reduce_windows(const SortedPlan& pl, const SortedBufs& b, int w0, int nw, int L, xyzz* wsum, hipStream_t st) {
     const int NB = pl.NB;
     const int nout = (1 << pl.lo_bits) + (NB >> pl.lo_bits);
     // lanes per output: 256 measured best at 2^20 and 2^22 (128 equal, 64 loses 12 %: the longer serial part per lane
     // costs more than the two tree levels it saves; gpurun sweep of BP_MSM_RC_T)
     int T = 256;
     if (const char* e = getenv("BP_MSM_RC_T")) T = atoi(e) == 64 || atoi(e) == 128 || atoi(e) == 256 ? atoi(e) : T;
-    hipLaunchKernelGGL(k_srt_rowcol2, dim3((unsigned)nout, (unsigned)nw), dim3((unsigned)T), 0, st, b.bstart, b.Bk, b.Pseg, NB, pl.L, pl.nseg,
+    hipLaunchKernelGGL(k_srt_rowcol2, dim3((unsigned)nout, (unsigned)nw), dim3((unsigned)T), 0, st, b.bstart, b.Bk, b.Pseg, NB, L, pl.nseg,
                        pl.lo_bits, w0, b.RC);
     hipLaunchKernelGGL(k_srt_window, dim3((unsigned)nw), dim3(256), 0, st, b.bstart, b.RC, NB, pl.lo_bits, w0, wsum);
     return hipGetLastError();
 }
 
 // Window sums of the sorted path.
-// ng <= 1: every window accumulated and reduced on st; wsum[0 .. W) are the window sums, *W_eff = W.
+// ng <= 1: every window accumulated and reduced on st; wsum[0 .. W) are the window sums, *W_eff = W, *c_eff = c.
 // ng >= 2 (needs ss): the windows are processed top-down in groups of gsz[0], gsz[1], ... windows.  The groups
-// accumulate back to back on st; each group's latency-bound tail runs beside the next groups' accumulation:
-// its bucket reduction on ss->st3 and the Horner chain over the finished groups (running value in
-// wsum[lowest finished window]) on ss->st2.  Only the last group's tail is exposed.  On return (stream order
-// of st) wsum[0] is the complete combination sum_w 2^(c w) S_w and *W_eff = 1.
+// accumulate back to back on st.  Side streams: st2 sorts the later groups' windows beside the first accumulation and
+// then runs the Horner chain (st4 is an alias of st2: the process has four hardware queues and a third side stream
+// shared st3's), st3 runs each finished group's bucket reduction.  Horner chain: V <- 2^(c gsz[g]) V is queued as soon
+// as V (the combination of the groups above g) exists, the group's own chain sum_w 2^(c (w - lo)) S_w + V follows its
+// reduction.  A last group of ONE window is not combined here: wsum[0] = S_0, wsum[1] = the doubled V, *W_eff = 2,
+// *c_eff = 0 - the caller's final kernel adds them on its way to the affine result.
+// Otherwise on return (stream order of st) wsum[0] is the complete combination and *W_eff = 1.
 hipError_t launch_msm_sorted(const affine_mem* pts, const affine_mem* lam, size_t n1, const int16_t* digits, size_t n2, const SortedPlan& pl,
-                             const SortedBufs& b, xyzz* wsum, hipStream_t st, const SortedStreams* ss, const int* gsz, int ng, int* W_eff) {
+                             const SortedBufs& b, xyzz* wsum, hipStream_t st, const SortedStreams* ss, const int* gsz, int ng, int* W_eff,
+                             int* c_eff) {
     const int W = pl.W;
     hipError_t e;
+    *c_eff = pl.c;
     if (!ss || ng <= 1) {
         srt_sort_windows(digits, n2, pl, b, 0, W, st);
-        srt_acc_windows(pts, lam, n1, pl, b, 0, W, st);
+        srt_acc_windows(pts, lam, n1, pl, b, 0, W, pl.L, pl.nseg, st);
         *W_eff = W;
-        return srt_reduce_windows(pl, b, 0, W, wsum, st);
+        return srt_reduce_windows(pl, b, 0, W, pl.L, wsum, st);
     }
-    // Counting sort: either every window up front, or (presort = false) the top group's windows first and the
-    // other groups' on st2, group by group, beside the accumulation of the groups before them.
-    const bool presort = getenv("BP_MSM_PRESORT") ? atoi(getenv("BP_MSM_PRESORT")) != 0 : false;
-    if (presort) {
-        srt_sort_windows(digits, n2, pl, b, 0, W, st);
-    } else {
-        srt_sort_windows(digits, n2, pl, b, W - gsz[0], gsz[0], st);
-        if ((e = hipEventRecord(ss->ev_fork, st)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(ss->st2, ss->ev_fork, 0)) != hipSuccess) return e;
-        for (int g = 1, top = W - gsz[0]; g < ng; g++) {
-            srt_sort_windows(digits, n2, pl, b, top - gsz[g], gsz[g], ss->st2);
-            if ((e = hipEventRecord(ss->ev_sorted[g], ss->st2)) != hipSuccess) return e;
-            top -= gsz[g];
-        }
+    // BP_MSM_LANES=<lanes> (tuning): longer segments per group, so that a group's accumulation launch has about that many
+    // lanes (2 * 256 * CUs = two waves per SIMD, leaving wave slots to the side streams).  Measured at 2^20: no gain - the
+    // side kernels slow the accumulation through the memory system (sort traffic evicts the points from the Infinity
+    // Cache), not through wave slots - so the default keeps the plan's segment length for every group.
+    size_t lanes = 0;
+    if (const char* e2 = getenv("BP_MSM_LANES")) lanes = (size_t)atol(e2) >= 4096 ? (size_t)atol(e2) : 0;
+    // the top group's windows are sorted first, the other groups' on st2, group by group, beside the accumulation
+    srt_sort_windows(digits, n2, pl, b, W - gsz[0], gsz[0], st);
+    if ((e = hipEventRecord(ss->ev_fork, st)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(ss->st2, ss->ev_fork, 0)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(ss->st4, ss->ev_fork, 0)) != hipSuccess) return e;
+    for (int g = 1, top = W - gsz[0]; g < ng; g++) {
+        srt_sort_windows(digits, n2, pl, b, top - gsz[g], gsz[g], ss->st2);
+        if ((e = hipEventRecord(ss->ev_sorted[g], ss->st2)) != hipSuccess) return e;
+        top -= gsz[g];
     }
-    int hi = W;
+    int hi = W, vidx = -1;
+    *W_eff = 1;
     for (int g = 0; g < ng; g++) {
         const int lo = hi - gsz[g];
-        if (g >= 1 && !presort && (e = hipStreamWaitEvent(st, ss->ev_sorted[g], 0)) != hipSuccess) return e;
-        srt_acc_windows(pts, lam, n1, pl, b, lo, hi - lo, st);
+        int L = pl.L;
+        if (lanes && pl.L >= 32) {
+            size_t l = ((size_t)gsz[g] * pl.npad + lanes - 1) / lanes;
+            l = (l + 7) & ~(size_t)7;
+            if (l > 256) l = 256;
+            if ((int)l > L) L = (int)l;
+        }
+        const int nseg = (int)((pl.npad + L - 1) / L);
+        if (g >= 1 && (e = hipStreamWaitEvent(st, ss->ev_sorted[g], 0)) != hipSuccess) return e;
+        srt_acc_windows(pts, lam, n1, pl, b, lo, hi - lo, L, nseg, st);
         if ((e = hipEventRecord(ss->ev_acc[g], st)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(ss->st3, ss->ev_acc[g], 0)) != hipSuccess) return e;
-        if ((e = srt_reduce_windows(pl, b, lo, hi - lo, wsum, ss->st3)) != hipSuccess) return e;
+        if ((e = srt_reduce_windows(pl, b, lo, hi - lo, L, wsum, ss->st3)) != hipSuccess) return e;
         if ((e = hipEventRecord(ss->ev_red[g], ss->st3)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(ss->st2, ss->ev_red[g], 0)) != hipSuccess) return e;
-        // wsum[lo] = sum over the windows >= lo (wsum[hi] holds the previous groups' combination)
-        hipLaunchKernelGGL(k_srt_horner_part, dim3(1), dim3(64), 0, ss->st2, wsum, lo, g ? hi + 1 : hi, pl.c);
+        if (vidx >= 0) hipLaunchKernelGGL(k_srt_dbl, dim3(1), dim3(64), 0, ss->st4, wsum, vidx, pl.c * gsz[g]);
+        if ((e = hipStreamWaitEvent(ss->st4, ss->ev_red[g], 0)) != hipSuccess) return e;
+        if (g == ng - 1 && gsz[g] == 1 && vidx == 1) {
+            *W_eff = 2;
+            *c_eff = 0;
+        } else {
+            hipLaunchKernelGGL(k_srt_horner_part, dim3(1), dim3(64), 0, ss->st4, wsum, lo, hi, pl.c, vidx);
+            vidx = lo;
+        }
         hi = lo;
     }
-    if ((e = hipEventRecord(ss->ev_join, ss->st2)) != hipSuccess) return e;
+    if ((e = hipEventRecord(ss->ev_join, ss->st4)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(st, ss->ev_join, 0)) != hipSuccess) return e;
-    *W_eff = 1;
     return hipGetLastError();
 }
 

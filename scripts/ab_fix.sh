@@ -1,7 +1,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread 2>&1 | tail -4
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o p --output-format csv -- python3 bench.py --no-rlc --no-bpplus --no-c2 --no-msm --no-cpu-baseline --no-tiled --steps 10 > /tmp/o.log 2>&1 || { tail -20 /tmp/o.log; exit 1; }
-f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); grep -E "k_bpv_fix<|k_bpv_msm" $f | sed 's/(.*)"/"/' | cut -c1-120
-tail -1 /tmp/o.log | python3 -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j['value'], j['kernel_ms'], [(r['proofs_per_launch_per_gpu'], round(r['ms_per_launch'],3)) for r in j['batch_sweep']])"
+for wp in 3 2; do
+  export BP_MSM_WPIPE=$wp
+  echo "=== WPIPE $wp"
+  bash scripts/msm_timeline.sh "5,4" 2>&1 | grep -v "^\[" | tail -95
+done
