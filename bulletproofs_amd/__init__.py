@@ -11,6 +11,10 @@ from ._lib import (  # noqa: F401
     generate_bases,
     msm_auto_window,
     noalloc_scratch_bytes,
+    proof_to_serde,
+    proof_from_serde,
+    SERDE_JSON,
+    SERDE_BINCODE,
     BP_EINVAL,
     KZEN_SEED,
     lib,

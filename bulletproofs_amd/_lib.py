@@ -58,6 +58,8 @@ EXPORTED_SYMBOLS = [
     "bp_ipa_verify",
     "bp_wipa_prove",
     "bp_wipa_verify",
+    "bp_proof_to_serde",
+    "bp_proof_from_serde",
     "bp_profile_enable",
     "bp_profile_reset",
     "bp_profile_get",
@@ -184,6 +186,10 @@ def lib():
     L.bp_wipa_prove.restype = i32
     L.bp_wipa_verify.argtypes = [vp, cp, cp, sz, cp, cp, cp, cp, cp, sz, i32, cp]
     L.bp_wipa_verify.restype = i32
+    L.bp_proof_to_serde.argtypes = [i32, i32, cp, sz, cp, sz, ctypes.POINTER(sz)]
+    L.bp_proof_to_serde.restype = i32
+    L.bp_proof_from_serde.argtypes = [i32, i32, cp, sz, cp, sz, ctypes.POINTER(sz)]
+    L.bp_proof_from_serde.restype = i32
     L.bp_profile_enable.argtypes = [vp, i32]
     L.bp_profile_enable.restype = None
     L.bp_profile_reset.argtypes = [vp]
@@ -517,6 +523,33 @@ class Context:
 
 def noalloc_scratch_bytes():
     return lib().bp_noalloc_scratch_bytes()
+
+
+SERDE_JSON, SERDE_BINCODE = 0, 1
+
+
+def proof_to_serde(kind, fmt, proof):
+    """Canonical proof bytes -> the serde encoding of RangeProof (kind 0) / RangeProofWIP (kind 1); host-only, needs no GPU."""
+    need = ctypes.c_size_t(0)
+    proof = bytes(proof)
+    rc = lib().bp_proof_to_serde(kind, fmt, proof, len(proof), None, 0, ctypes.byref(need))
+    if need.value == 0:
+        _check(rc)
+    out = ctypes.create_string_buffer(need.value)
+    _check(lib().bp_proof_to_serde(kind, fmt, proof, len(proof), out, need.value, ctypes.byref(need)))
+    return out.raw[:need.value]
+
+
+def proof_from_serde(kind, fmt, data):
+    """serde encoding (JSON text / bincode bytes) -> canonical proof bytes; host-only, needs no GPU."""
+    need = ctypes.c_size_t(0)
+    data = bytes(data)
+    rc = lib().bp_proof_from_serde(kind, fmt, data, len(data), None, 0, ctypes.byref(need))
+    if need.value == 0:
+        _check(rc)
+    out = ctypes.create_string_buffer(need.value)
+    _check(lib().bp_proof_from_serde(kind, fmt, data, len(data), out, need.value, ctypes.byref(need)))
+    return out.raw[:need.value]
 
 
 def msm_auto_window(n):

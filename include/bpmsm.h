@@ -305,6 +305,25 @@ int bp_wipa_prove(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t 
 int bp_wipa_verify(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* hi_tag_xy, size_t n, const uint8_t g_pt[64], const uint8_t h_pt[64],
                    const uint8_t P_xy[64], const uint8_t y_be[32], const uint8_t* arg, size_t arg_len, int mode, uint8_t* verdict);
 
+/* Wire formats - the serde encodings of the reference's proof structs, converted to / from the canonical
+ * proof bytes above.  `#[derive(Serialize, Deserialize)]` on RangeProof (range_proof.rs:32-42), InnerProductArg
+ * (inner_product.rs:27-33), RangeProofWIP (range_proof_wip.rs:93-97), WeightedInnerProdArg (weighted_inner_product.rs:35-44)
+ * over curv-kzen 0.10's impls: Point = {curve: "secp256k1", point: 33-byte SEC1 bytes}, Scalar = {curve, scalar: 32 bytes},
+ * BigInt = hex string of the minimal big-endian magnitude (human-readable formats) / byte string (binary formats).
+ * curv is not vendored and the reference never serialises a proof, so these leaf encodings are a restatement of curv's
+ * published impls: PARITY UNPINNED.  Host code only (no GPU, no context).
+ *   kind   : 0 = RangeProof, 1 = RangeProofWIP
+ *   format : BP_SERDE_JSON (serde_json::to_string / from_str; fields by name, any order and whitespace on input),
+ *            BP_SERDE_BINCODE (bincode 1.x default options: declaration order, u64 little-endian lengths).
+ * Both return BP_EINVAL for a non-canonical length, a missing / mistyped field, another curve name, a point that is not
+ * 33 bytes with a 02/03 prefix, a BigInt above 256 bits, trailing bytes, or a too small output buffer - in the last case
+ * *out_len / *proof_len still receive the size needed (call once with cap = 0 to size the buffer).  On-curve checks stay
+ * with the verifiers (verdict BP_VERDICT_MALFORMED), as curv's deserialiser and `verify` split them. */
+#define BP_SERDE_JSON 0
+#define BP_SERDE_BINCODE 1
+int bp_proof_to_serde(int kind, int format, const uint8_t* proof, size_t proof_len, uint8_t* out, size_t cap, size_t* out_len);
+int bp_proof_from_serde(int kind, int format, const uint8_t* in, size_t in_len, uint8_t* proof_out, size_t cap, size_t* proof_len);
+
 /* Per-kernel device timing with HIP events on the context's own stream (what bench.py's roofline
  * block reads; no reference counterpart).  Kernel ids: 0 = bpv_decompress, 1 = bpv_scalars,
  * 2 = bpv_msm.  Times accumulate from bp_profile_enable(ctx, 1) until bp_profile_reset. */

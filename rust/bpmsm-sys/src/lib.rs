@@ -130,6 +130,12 @@ extern "C" {
     pub fn bp_wipa_verify(ctx: *mut bp_ctx, g_xy: *const u8, hi_tag_xy: *const u8, n: usize, g_pt: *const u8, h_pt: *const u8,
                           p_xy: *const u8, y_be: *const u8, arg: *const u8, arg_len: usize, mode: c_int, verdict: *mut u8) -> c_int;
 
+    // serde wire formats of RangeProof / RangeProofWIP <-> canonical proof bytes (kind 0 / 1; format 0 = JSON, 1 = bincode)
+    pub fn bp_proof_to_serde(kind: c_int, format: c_int, proof: *const u8, proof_len: usize, out: *mut u8, cap: usize,
+                             out_len: *mut usize) -> c_int;
+    pub fn bp_proof_from_serde(kind: c_int, format: c_int, input: *const u8, in_len: usize, proof_out: *mut u8, cap: usize,
+                               proof_len: *mut usize) -> c_int;
+
     // RangeProofWIP::{prove, verify, aggregated_verify} (range_proof_wip.rs:101-609)
     pub fn bp_wip_rangeproof_prove(ctx: *mut bp_ctx, gens: *const bp_gens, n_bits: c_int, secrets_be: *const u8, blindings_be: *const u8,
                                    m: c_int, tape: *const u8, tape_len: usize, proof_out: *mut u8, proof_cap: usize,

@@ -409,3 +409,26 @@ def test_bpplus_mixed_aggregation_sizes_in_one_call(ctx, oracle_c):
     finally:
         for g in per_m_gens.values():
             g.close()
+
+
+@pytest.mark.parametrize("fmt", [bpa.SERDE_JSON, bpa.SERDE_BINCODE])
+def test_serde_wire_format_feeds_the_verifier(ctx, fmt):
+    """a proof that arrives in the serde encoding of `RangeProof` (curv-kzen 0.10's Point / Scalar / BigInt
+    impls as restated in oracle/serde_curv.py - parity unpinned) is converted by bp_proof_from_serde and verified; a
+    tampered one keeps its oracle verdict through the same route."""
+    from oracle import encoding, serde_curv
+    case = bp_cases()[0]
+    n, m = case["n"], case["m"]
+    gens = _gens(ctx, n, m, window_bits=8)
+    try:
+        wires, coms, want = [], [], []
+        for rec in [case] + [t for t in case["tampered"] if VERDICT_CODE[t["verdict"]] != 255]:
+            obj = encoding.decode_bp(bytes.fromhex(rec["proof"]))
+            wires.append(serde_curv.to_json(obj) if fmt == bpa.SERDE_JSON else serde_curv.to_bincode(obj))
+            coms.append(b"".join(bytes.fromhex(c) for c in rec["commitments"]))
+            want.append(VERDICT_CODE[rec["verdict"]])
+        proofs = [bpa.proof_from_serde(0, fmt, w) for w in wires]
+        assert ctx.rangeproof_verify_batch(gens, n, m, b"".join(proofs), b"".join(coms)) == want
+        assert want[0] == 0 and any(v != 0 for v in want)
+    finally:
+        gens.close()
