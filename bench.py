@@ -46,14 +46,14 @@ MAD32_PER_POINT_MSM = 11833.0       # SURVEY.md 8(d), C5 model (2^20 points, c =
 #   whole bp_msm_device pipeline at 2^20 points:           157.0 fp_mul + 39.4 fp_sqr per point
 EXEC_MAD32_PER_PROOF_MSM = 2.907e6
 EXEC_MAD32_PER_POINT_MSM = 18578.0
-# HBM-side traffic of one k_bpv_msm launch at the default configuration (65536 proofs, auto lanes, 20-bit table
-# windows), from the separate --pmc passes in profiles/r01_pmc_read.csv / r01_pmc_write.csv:
-# TCC_EA0_RDREQ 143.80e6 x 64 B (64-byte gathers of table entries and lane-private window tables, not the
-# 16-B/lane streaming pattern the guide's x2 correction was calibrated on: RDREQ x 64 B already matches the
-# algorithmic gather bytes, 1690 table entries x 64 B per proof + the ~1000 window-table reads, so no doubling)
-# + TCC_EA0_WRREQ 36.73e6 x 64 B + 19.70e6 x 32 B (the lane-private window tables).  12.2 GB in 13.7 ms =
-# 0.89 TB/s, 11 % of the HBM peak: the kernel is VALU-bound.
-PMC_TRAFFIC_BYTES_DEFAULT = 143.80e6 * 64 + 36.73e6 * 64 + 19.70e6 * 32
+# HBM-side traffic of one verification MSM (the launch pair k_bpv_fix + k_bpv_msm) at the default configuration (65536
+# distinct proofs, auto lanes, 20-bit table windows), from the separate --pmc passes in profiles/r02_pmc_read.csv /
+# r02_pmc_write.csv:  k_bpv_fix TCC_EA0_RDREQ 75.37e6 x 64 B (the 1690 table gathers per proof are 110.8e6 lines: a third
+# hit in L2) + 0.15e6 x 64 B written;  k_bpv_msm RDREQ 88.88e6 x 64 B + WRREQ 39.38e6 x 64 B + 18.29e6 x 32 B (the
+# lane-private window tables of the proof-specific points, built in and re-read from global scratch).  64-byte gathers, not
+# the 16-B/lane streaming pattern the guide's x2 correction was calibrated on: RDREQ x 64 B already matches the algorithmic
+# gather bytes, so no doubling.  13.6 GB in 14.2 ms = 0.96 TB/s, 12 % of the HBM peak: the kernels are VALU-bound.
+PMC_TRAFFIC_BYTES_DEFAULT = (75.37e6 + 88.88e6) * 64 + 0.15e6 * 64 + 39.38e6 * 64 + 18.29e6 * 32
 
 
 # Rehearsal of the multi-rank path on a ONE-GPU box (BENCH_REHEARSAL=1 under torch.distributed.run): every rank uses
@@ -78,10 +78,10 @@ def dist_setup(world, local_rank):
 
 
 
-# HBM-side traffic of one k_srt_acc launch of the 2^20 raw MSM (two launches per MSM: 5 + 4 windows), from the --pmc passes in
-# profiles/r01_msm_pmc_read.csv / r01_msm_pmc_write.csv: TCC_EA0_RDREQ 15.40e6 x 64 B (64-byte point gathers + the sorted
-# entries, one line per 8 entries) + TCC_EA0_WRREQ 1.145e6 x 64 B + 0.182e6 x 32 B (bucket / segment partial sums).
-PMC_TRAFFIC_MSM_ACC_BYTES = 15.40e6 * 64 + 1.145e6 * 64 + 0.182e6 * 32
+# HBM-side traffic of one k_srt_acc launch of the 2^20 raw MSM (three launches per MSM: 5 + 3 + 1 windows; average), from the
+# --pmc passes in profiles/r02_msm_pmc_read.csv / r02_msm_pmc_write.csv: TCC_EA0_RDREQ 12.09e6 x 64 B (64-byte point gathers +
+# the sorted entries, one line per 8 entries) + TCC_EA0_WRREQ 0.906e6 x 64 B + 0.139e6 x 32 B (bucket / segment partial sums).
+PMC_TRAFFIC_MSM_ACC_BYTES = 12.09e6 * 64 + 0.906e6 * 64 + 0.139e6 * 32
 
 
 def parse():
@@ -107,6 +107,7 @@ def parse():
     ap.add_argument("--prove-threads", type=int, default=8, help="--workload prove: contexts in flight for the throughput figure")
     ap.add_argument("--skip-check", action="store_true", help="timing experiments only: do not compare verdicts")
     ap.add_argument("--cpu-sample", type=int, default=1200, help="proofs verified by the CPU baseline")
+    ap.add_argument("--cpu-worker", type=float, default=0, help=argparse.SUPPRESS)  # one process of cpu_baseline's all-cores leg
     return ap.parse_args()
 
 
@@ -116,8 +117,8 @@ def load_batch():
     return b
 
 
-def cpu_baseline(batch, sample):
-    """Oracle aggregated_verify (Python scalar derivation + C term-by-term MSM), one core."""
+def _cpu_verify_loop(batch, sample, seconds):
+    """(proofs verified, seconds) of the oracle's aggregated_verify over the golden C3 batch on this core."""
     import subprocess
     from oracle import ec, encoding
     if not ec.have_c():
@@ -141,12 +142,77 @@ def cpu_baseline(batch, sample):
         com = [ec.dec64(coms[i * 64:(i + 1) * 64])]
         n_ok += p.aggregated_verify(g_vec, h_vec, G, H, com, 64) == "Ok"
         done += 1
-        if time.perf_counter() - t0 > 20:
+        if time.perf_counter() - t0 > seconds:
             break
     dt = time.perf_counter() - t0
     assert n_ok == done
-    return {"value": done / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
-            "sample": "%d n=64 m=1 proofs, oracle aggregated_verify (term-by-term MSM in C, as range_proof.rs:772-774)" % done}
+    return done, dt
+
+
+def _openssl_mul_rate(seconds=2.0):
+    """EC_POINT_mul(secp256k1, variable point) per second on one core through libcrypto, or None when it is absent."""
+    import ctypes
+    import ctypes.util
+    name = ctypes.util.find_library("crypto")
+    if not name:
+        return None
+    try:
+        L = ctypes.CDLL(name)
+        vp = ctypes.c_void_p
+        for f, a in (("EC_GROUP_new_by_curve_name", [ctypes.c_int]), ("EC_POINT_new", [vp]), ("BN_new", []), ("BN_CTX_new", []),
+                     ("EC_GROUP_get0_generator", [vp])):
+            getattr(L, f).restype = vp
+            getattr(L, f).argtypes = a
+        L.EC_POINT_mul.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.BN_bin2bn.argtypes = [ctypes.c_char_p, ctypes.c_int, vp]
+        L.BN_bin2bn.restype = vp
+        grp = L.EC_GROUP_new_by_curve_name(714)  # NID_secp256k1
+        bctx = L.BN_CTX_new()
+        P, R = L.EC_POINT_new(grp), L.EC_POINT_new(grp)
+        k = L.BN_bin2bn(shake(b"bpmsm-openssl-k", 32), 32, None)
+        L.EC_POINT_mul(grp, P, k, None, None, bctx)  # P = k G: a variable point
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(200):
+                if L.EC_POINT_mul(grp, R, None, P, k, bctx) != 1:
+                    return None
+            n += 200
+        return n / (time.perf_counter() - t0)
+    except Exception:
+        return None
+
+
+def cpu_baseline(batch, sample):
+    """Oracle aggregated_verify (Python scalar derivation + C term-by-term MSM): one core (`value`, the reference is
+    single-threaded), the same loop on every core of this box's share as separate processes (`all_cores`), and
+    libcrypto's EC_POINT_mul rate turned into proofs/s by the reference's 147 multiplications per verification."""
+    import subprocess
+    r = _cpu_verify_loop(batch, sample, 20)
+    if r is None:
+        return None
+    done, dt = r
+    out = {"value": done / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
+           "sample": "%d n=64 m=1 proofs, oracle aggregated_verify (term-by-term MSM in C, as range_proof.rs:772-774)" % done}
+    ncores = min(16, os.cpu_count() or 1)  # the GPU box's share is 16 cores whatever os.cpu_count() says
+    try:
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "8"], stdout=subprocess.PIPE, text=True)
+                 for _ in range(ncores)]
+        tot, tmax = 0, 0.0
+        for p in procs:
+            o, _ = p.communicate(timeout=120)
+            d, t = o.strip().split()[-2:]
+            tot += int(d)
+            tmax = max(tmax, float(t))
+        out["all_cores"] = {"value": tot / tmax, "unit": "proofs/s", "cores": ncores,
+                            "sample": "%d proofs over %d processes of the same loop, %.1f s" % (tot, ncores, tmax)}
+    except Exception as e:  # a baseline, never a reason to lose the bench line
+        out["all_cores"] = {"error": repr(e)[:200]}
+    rate = _openssl_mul_rate()
+    if rate:
+        out["openssl_ec_point_mul"] = {"mul_per_s": rate, "proofs_per_s_equiv": rate / 147.0, "cores": 1,
+                                       "what": "libcrypto EC_POINT_mul on a variable secp256k1 point, one core; a verification is 147 "
+                                               "such multiplications + 146 additions in the reference (range_proof.rs:772-774)"}
+    return out
 
 
 def bench_msm(args):
@@ -248,7 +314,7 @@ def bench_msm(args):
             "roofline": {"bound": "valu_int32_mad", "kernel": "whole bp_msm_device pipeline (dominant kernel k_srt_acc)", "achieved": mpts * 1e6 * mad_per_point / world / 1e12,
                          "peak": PEAK_MAD32_PER_S / 1e12, "unit": "TMAD32/s", "frac": mpts * 1e6 * mad_per_point / world / PEAK_MAD32_PER_S,
                          "traffic": PMC_TRAFFIC_MSM_ACC_BYTES if (args.msm_log2 == 20 and world == 1) else None,
-                         "traffic_unit": "bytes per k_srt_acc launch, two launches per MSM (PMC, profiles/r01_msm_pmc_*.csv); algorithmic: "
+                         "traffic_unit": "bytes per k_srt_acc launch, three launches per MSM (PMC, profiles/r02_msm_pmc_*.csv); algorithmic per MSM: "
                                          "9.4 M entries x (8 B entry + 64 B point) = 0.68 GB"}}), flush=True)
     ctx.close()
     if world > 1:
@@ -509,6 +575,10 @@ def msm_side(ctx, dev, log2n, steps):
 
 def main():
     args = parse()
+    if args.cpu_worker > 0:  # CPU only: one process of cpu_baseline's all-cores leg
+        done, dt = _cpu_verify_loop(load_batch(), 1 << 30, args.cpu_worker)
+        print(done, "%.3f" % dt)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args))
     if REHEARSAL_DRY:
@@ -794,7 +864,7 @@ def main():
             "c2_batch": c2,
             "roofline": {
                 "bound": "valu_int32_mad",
-                "kernel": "k_bpv_msm",
+                "kernel": "k_bpv_fix + k_bpv_msm (the verification MSM: fixed-generator half and proof-specific half, launched back to back)",
                 "achieved": executed / 1e12,
                 "peak": PEAK_MAD32_PER_S / 1e12,
                 "unit": "TMAD32/s",

@@ -17,5 +17,6 @@ timeout -k 10 300 python3 bench.py --workload prove --steps 8 > $O/prove_latency
 timeout -k 10 300 python3 scripts/experiments/bigtable_test.py 4096 12,14,16 > $O/bigtable.txt 2> $O/bigtable.err
 timeout -k 10 120 ./bench_micro/ecops > $O/ecops.jsonl 2> $O/ecops.err
 timeout -k 10 120 ./bench_micro/peak_mad32 > $O/peak_mad32.jsonl 2> $O/peak.err
-for d in kt pmc_rd pmc_wr pmc_valu msm_kt msm_pmc_rd msm_pmc_wr; do f=$(ls $O/$d/*_results.db); m=pmc; case $d in kt|msm_kt) m=stats;; esac; python3 profiles/summarize.py $m $f $O/$d.csv; done
+for d in kt pmc_rd pmc_wr pmc_valu msm_kt msm_pmc_rd msm_pmc_wr; do f=$(ls $O/$d/*_results.db); m=pmc; case $d in kt|msm_kt) m=stats;; esac; python3 profiles/summarize.py $m $f $O/$d.csv; rm -rf $O/$d; done  # raw rocprof databases stay on the box (gpurun merges back <= 64 MiB)
+du -sh $O
 echo PROFILES_OK
