@@ -86,6 +86,7 @@ hipError_t launch_wipv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, 
                                        const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fqm* scF, fq* varS, fq* chal,
                                        fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st, int ibase, int nm_tab);
 size_t bpv_msm_vartab_bytes(int tp, size_t nproofs);
+int bpv_slice_lanes(int nv);
 
 
 // msm_batch.hip

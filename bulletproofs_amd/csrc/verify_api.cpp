@@ -263,7 +263,7 @@ struct VerifySizes {
         return t;
     }
 };
-static VerifySizes verify_ws_sizes(const bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, size_t nproofs, int wip) {
+static VerifySizes verify_ws_sizes(const bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, size_t nproofs, int wip, bool allow_slice = true) {
     const int NPT = (wip ? 3 : 4) + 2 * k + m, NV = (wip ? 2 : 3) + 2 * k + m;
     VerifySizes z;
     z.pts = nproofs * NPT * sizeof(affine_mem);
@@ -274,8 +274,15 @@ static VerifySizes verify_ws_sizes(const bp_ctx* ctx, const bp_gens* gens, int n
     z.fixres = nproofs * 2 * (sizeof(xyzz) + sizeof(affine_mem));
     // lanes per proof: fewer lanes share more doubling chains (less work) but need more proofs in
     // flight to fill 256 CUs x 4 SIMDs x 2 waves
+    // Batches too small to give every SIMD even one wave that way are latency-bound: four lanes per proof-specific point
+    // (k_bpv_msm_slice, tp < 0 = minus its lanes per proof; measured on n=64 m=1: 512 proofs 1.21 -> 0.93 ms, 1024 proofs
+    // 1.20 -> 0.95 ms, 2048 proofs 1.34 -> 1.55 ms, hence the 65536-lane limit).  bp_verify_set_lanes(ctx, -4) forces that
+    // kernel; allow_slice = false keeps the smaller workspace of the ladder kernel (no-allocation entry point).
     int tp = ctx->verify_lanes;
-    if (tp != 2 && tp != 4 && tp != 8 && tp != 16 && tp != 32 && tp != 64) {
+    const int slice_lpp = bpv_slice_lanes(NV);
+    if (allow_slice && (tp == -4 || (tp == 0 && nproofs * (size_t)slice_lpp <= 65536))) {
+        tp = -slice_lpp;
+    } else if (tp != 2 && tp != 4 && tp != 8 && tp != 16 && tp != 32 && tp != 64) {
         tp = nproofs >= 65536 ? 2 : (nproofs >= 32768 ? 4 : (nproofs >= 12288 ? 8 : 16));
         // aggregated proofs (n*m >= 512): the table part dominates and has no per-lane overhead, so take enough
         // lanes for two waves per SIMD (131072 lanes) even with few proofs in the batch
@@ -409,7 +416,9 @@ int bp_rangeproof_verify_batch_device_noalloc(bp_ctx* ctx, const bp_gens* gens, 
         set_error_msg("no-allocation entry point: this device's scratch address was not resolved at bp_ctx_create");
         return BP_EHIP;
     }
-    const VerifySizes z = verify_ws_sizes(ctx, gens, n_bits, m, k, nproofs, 0);
+    VerifySizes z = verify_ws_sizes(ctx, gens, n_bits, m, k, nproofs, 0);
+    // the small-batch kernel's window tables take twice the workspace per proof: fall back to the ladder kernel before refusing
+    if (z.tp < 0 && z.total() > (size_t)BP_NOALLOC_SCRATCH_BYTES) z = verify_ws_sizes(ctx, gens, n_bits, m, k, nproofs, 0, false);
     if (nproofs > ((size_t)1 << 24) || z.total() > (size_t)BP_NOALLOC_SCRATCH_BYTES) {
         char msg[200];
         snprintf(msg, sizeof msg, "no-allocation entry point: the batch needs %zu bytes of workspace, the fixed scratch holds %zu; split the batch",

@@ -225,6 +225,61 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
     }
 }
 
+// Small batches (latency-bound: too few proofs to fill the SIMDs with one ladder per lane): FOUR lanes per proof-specific point
+// (ec_mul_glv_slice: GLV half x window range, the upper range on the base 2^68 P), LPP lanes per proof.  The longest lane does
+// 128 doublings + 17 additions instead of 128 doublings + 66 additions, and a 512-proof batch fills 512 waves instead of 128.
+// More total work than k_bpv_msm (every slice pays for its own doubling chain), so only chosen when the batch cannot fill
+// two waves per SIMD anyway (bpv_slice_lanes).
+template <int LPP>
+__global__ __launch_bounds__(256) void k_bpv_msm_slice(int m, int k, size_t nproofs, const affine_mem* __restrict__ pts,
+                                                        const xyzz* __restrict__ fixpart, const fq* __restrict__ varS, xyzz* __restrict__ vartab,
+                                                        const int* __restrict__ bad, uint8_t* __restrict__ verdicts, int wip) {
+    __shared__ xyzz red[256];
+    const int tid = threadIdx.x;
+    const int lane = tid % LPP;
+    const size_t pr = (size_t)blockIdx.x * (256 / LPP) + tid / LPP;
+    const bool active = pr < nproofs && !bad[pr];
+    const int NPT = (wip ? 3 : 4) + 2 * k + m;
+    const int NV = (wip ? 2 : 3) + 2 * k + m;
+    xyzz acc = xyzz_inf();
+    if (active) {
+        if (lane == 0) acc = fixpart[pr];
+        const affine_mem* P = pts + pr * NPT;
+        const fq* vs = varS + pr * (size_t)NV;
+        xyzz* tab = vartab + ((size_t)blockIdx.x * 256 + tid) * ECMUL_NT;
+        for (int idx = lane; idx < 4 * NV; idx += LPP) {
+            const int v = idx >> 2, slice = idx & 3;
+            // variable point order: S, L_0.., R_0.., V_0.., T1, T2  ->  index into pts (as in k_bpv_msm)
+            const int pi = wip ? 1 + v : (v == 0) ? 1 : (v < 1 + 2 * k + m) ? (3 + v) : (v == 1 + 2 * k + m ? 2 : 3);
+            xyzz t = ec_mul_glv_slice(affine_load(P[pi]), vs[v], slice, tab);
+            xyzz_add(acc, t);
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int off = LPP / 2; off >= 1; off >>= 1) {
+        if (lane < off) {
+            xyzz v = red[tid];
+            xyzz o = red[tid + off];
+            xyzz_add(v, o);
+            red[tid] = v;
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && pr < nproofs) {
+        uint8_t verdict;
+        if (bad[pr]) {
+            verdict = 255;
+        } else {
+            xyzz r = red[tid];
+            affine A = affine_load(pts[pr * NPT]);
+            bool eq = !xyzz_is_inf(r) && fp_eq(r.X, fp_mul(A.x, r.ZZ)) && fp_eq(r.Y, fp_mul(A.y, r.ZZZ));
+            verdict = eq ? 0 : 3;
+        }
+        verdicts[pr] = verdict;
+    }
+}
+
 hipError_t launch_bpv_decompress(const uint8_t* proofs, size_t proof_len, const uint8_t* coms_xy, int k, int m, size_t nproofs, affine_mem* pts,
                                  int* bad, hipStream_t st) {
     size_t total = nproofs * (size_t)(4 + 2 * k + m);
@@ -241,7 +296,18 @@ hipError_t launch_wipv_decompress(const uint8_t* proofs, size_t proof_len, const
 }
 // lanes per proof -> proof-specific points per lane and pass
 static int bpv_ppl(int tp) { return tp == 2 ? 8 : (tp == 4 ? 4 : (tp == 8 ? 2 : 1)); }
+// lanes per proof of the four-lanes-per-point kernel for NV proof-specific points (a power of two, at most one workgroup)
+int bpv_slice_lanes(int nv) {
+    int lpp = 16;
+    while (lpp < 4 * nv && lpp < 256) lpp *= 2;
+    return lpp;
+}
+// tp > 0: lanes per proof of k_bpv_msm; tp < 0: k_bpv_msm_slice with -tp lanes per proof
 size_t bpv_msm_vartab_bytes(int tp, size_t nproofs) {
+    if (tp < 0) {
+        size_t blocks = (nproofs * (size_t)(-tp) + 255) / 256;
+        return blocks * 256 * ECMUL_NT * sizeof(xyzz);
+    }
     size_t blocks = (nproofs + (256 / tp) - 1) / (256 / tp);
     return blocks * 256 * bpv_ppl(tp) * (ECMUL_SLOTS * sizeof(xyzz) + ECMUL_NT * sizeof(affine_mem) + ECMUL_DIGB);
 }
@@ -258,7 +324,7 @@ hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, cons
                           int wip, int nm_tab) {
     const int nm = n_bits * m;
     const int shiftW = nm_tab > nm ? (nm_tab - nm) * W : 0;
-    const int tf = bpv_fix_lanes(tp, nproofs, nm);
+    const int tf = bpv_fix_lanes(tp < 0 ? 16 : tp, nproofs, nm);
     unsigned fblocks = (unsigned)((nproofs + (256 / tf) - 1) / (256 / tf));
 #define BPV_FIX(TP) hipLaunchKernelGGL((k_bpv_fix<TP>), dim3(fblocks), dim3(256), 0, st, nm, nproofs, table, c, W, digF, bad, shiftW, fixpart)
     if (tf == 4)
@@ -274,6 +340,23 @@ hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, cons
     else
         BPV_FIX(2);
 #undef BPV_FIX
+    if (tp < 0) {
+        const int lpp = -tp;
+        unsigned sblocks = (unsigned)((nproofs * (size_t)lpp + 255) / 256);
+#define BPV_SLICE(LPP) hipLaunchKernelGGL((k_bpv_msm_slice<LPP>), dim3(sblocks), dim3(256), 0, st, m, k, nproofs, pts, fixpart, varS, vartab, bad, verdicts, wip)
+        if (lpp == 16)
+            BPV_SLICE(16);
+        else if (lpp == 32)
+            BPV_SLICE(32);
+        else if (lpp == 64)
+            BPV_SLICE(64);
+        else if (lpp == 128)
+            BPV_SLICE(128);
+        else
+            BPV_SLICE(256);
+#undef BPV_SLICE
+        return hipGetLastError();
+    }
     unsigned blocks = (unsigned)((nproofs + (256 / tp) - 1) / (256 / tp));
     // vartab = [XYZZ construction slots | finished 64-byte tables | digits], each per lane
     affine_mem* varaff = reinterpret_cast<affine_mem*>(vartab + (size_t)blocks * 256 * bpv_ppl(tp) * ECMUL_SLOTS);

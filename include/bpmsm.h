@@ -184,7 +184,8 @@ int bp_rangeproof_verify_batch_rlc(bp_ctx* ctx, const bp_gens* gens, int n_bits,
                                    const uint8_t* coms_xy, size_t nproofs, const uint8_t seed[32], uint8_t* verdicts, int* used_fallback);
 int bp_rangeproof_verify_batch_rlc_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
                                           const void* d_coms_xy, size_t nproofs, const uint8_t seed[32], void* d_verdicts, int* used_fallback);
-/* Tuning knob: lanes per proof in the verifier's MSM kernel (4, 8, 16, 32 or 64; 0 = chosen by batch size). */
+/* Tuning knob: lanes per proof in the verifier's MSM kernel (2, 4, 8, 16, 32 or 64; 0 = chosen by batch size; -4 = the
+ * small-batch kernel with four lanes per proof-specific point, which 0 picks by itself when the batch is latency-bound). */
 void bp_verify_set_lanes(bp_ctx* ctx, int lanes);
 
 /* bp_scalar_mul_batch — n independent out[i] = scalars[i] * points[i].

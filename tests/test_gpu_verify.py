@@ -16,7 +16,7 @@ def _gens(ctx, n, m, window_bits=0):
 
 
 @pytest.mark.parametrize("idx", range(5))
-@pytest.mark.parametrize("lanes", [4, 8, 16, 64])
+@pytest.mark.parametrize("lanes", [4, 8, 16, 64, -4])
 def test_bp_cases_valid_and_tampered(ctx, idx, lanes):
     case = bp_cases()[idx]
     n, m = case["n"], case["m"]
