@@ -70,6 +70,25 @@ BP_HD affine_mem affine_store(const affine& p) {
     m.y = fp_to_words(p.y);
     return m;
 }
+// 64-byte gather as four 16-byte loads.  Every array of affine_mem in this library starts on a 256-byte boundary (hipMalloc,
+// the carved workspaces), so an element is 64-byte aligned; the struct itself only promises 4, which makes the compiler split
+// a plain copy into overlapping dwordx3/x4 loads and patch the pieces together with moves that wait for the first piece right
+// after it was issued.  Unconditional by design: software-pipelined loops call it outside any branch, so that the number of
+// loads in flight is the same on every path and the waits are exact s_waitcnt vmcnt(N).
+BP_HD affine_mem affine_mem_ld(const affine_mem* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4* q = reinterpret_cast<const uint4*>(__builtin_assume_aligned(p, 64));
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    affine_mem m;
+    m.x.w[0] = a.x, m.x.w[1] = a.y, m.x.w[2] = a.z, m.x.w[3] = a.w;
+    m.x.w[4] = b.x, m.x.w[5] = b.y, m.x.w[6] = b.z, m.x.w[7] = b.w;
+    m.y.w[0] = c.x, m.y.w[1] = c.y, m.y.w[2] = c.z, m.y.w[3] = c.w;
+    m.y.w[4] = d.x, m.y.w[5] = d.y, m.y.w[6] = d.z, m.y.w[7] = d.w;
+    return m;
+#else
+    return *p;
+#endif
+}
 BP_HD bool affine_mem_is_inf(const affine_mem& m) { return fp_words_is_zero(m.x) && fp_words_is_zero(m.y); }
 
 BP_HD bool xyzz_is_inf(const xyzz& p) { return fp_raw_is_zero(p.ZZ); }

@@ -203,32 +203,40 @@ BP_HD xyzz ec_mul_glv_multi(LoadP loadP, LoadK loadK, int cnt, xyzz* tab, affine
     };
     auto digit_of = [&](const uint32_t dw[(DW + 3) / 4], int t) { return (int)(int8_t)(dw[t >> 2] >> (8 * (t & 3))); };
     // (a zero digit fetches entry 0 and ignores it: no branch around the load, nothing uninitialised)
-    auto fetch = [&](int d, int t, affine_mem& e) { e = atab[(t >> 1) * ECMUL_NT + (d == 0 ? 0 : (d < 0 ? -d : d) - 1)]; };
-    const int nt = 2 * cnt;
+    auto fetch = [&](int d, int t) { return affine_mem_ld(atab + (t >> 1) * ECMUL_NT + (d == 0 ? 0 : (d < 0 ? -d : d) - 1)); };
+    const int nt = 2 * cnt;  // even: the k1 / k2 halves of cnt points
     uint32_t dcur[(DW + 3) / 4], dnext[(DW + 3) / 4];
     load_digits(ECMUL_WINS - 1, dcur);
+    for (int i = 0; i < (DW + 3) / 4; i++) dnext[i] = 0;
     xyzz acc = xyzz_inf();
+    // Two additions per trip through two entry buffers: A holds an even term (k1 half: the point itself), B an odd one (k2 half:
+    // x times beta).  Every fetch is unconditional and outside any branch, and nothing is copied between buffers, so each
+    // addition starts with the NEXT entry's four loads in flight and waits only for its own (exact vmcnt); the first entry
+    // of the next window is fetched during the last addition of this one and stays in flight during the four doublings.
+    // (The one-buffer form `en = em; if (t + 1 < nt) fetch(en)` compiled to a wait for the first piece of the new entry
+    // right after its loads were issued - a memory round trip in front of every addition at two waves per SIMD.)
+    int d0 = digit_of(dcur, 0);
+    affine_mem A = fetch(d0, 0), B;
     for (int w = ECMUL_WINS - 1; w >= 0; w--) {
         if (w > 0) load_digits(w - 1, dnext);  // in flight during this window
-        int d = digit_of(dcur, 0);
-        affine_mem em;
-        fetch(d, 0, em);  // in flight during the doublings
         if (w != ECMUL_WINS - 1) acc = xyzz_dbl_n(acc, 4);
-        for (int t = 0; t < nt; t++) {
-            int dn = 0;
-            affine_mem en = em;
-            if (t + 1 < nt) {
-                dn = digit_of(dcur, t + 1);
-                fetch(dn, t + 1, en);  // in flight during the addition below
-            }
-            if (d != 0) {
-                affine e = affine_load(em);
-                if (t & 1) e.x = fp_mul(e.x, beta);
-                if (d < 0) e.y = fp_neg(e.y);
+        for (int t = 0; t < nt; t += 2) {
+            const int d1 = digit_of(dcur, t + 1);
+            B = fetch(d1, t + 1);
+            if (d0 != 0) {
+                affine e = affine_load(A);
+                if (d0 < 0) e.y = fp_neg(e.y);
                 xyzz_madd(acc, e);
             }
-            d = dn;
-            em = en;
+            const bool more = t + 2 < nt;
+            d0 = more ? digit_of(dcur, t + 2) : digit_of(dnext, 0);  // w == 0: dnext is stale, the entry is never used
+            A = fetch(d0, more ? t + 2 : 0);
+            if (d1 != 0) {
+                affine e = affine_load(B);
+                e.x = fp_mul(e.x, beta);
+                if (d1 < 0) e.y = fp_neg(e.y);
+                xyzz_madd(acc, e);
+            }
         }
         for (int i = 0; i < (DW + 3) / 4; i++) dcur[i] = dnext[i];
     }

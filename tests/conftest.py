@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through libbpmsm.so's C ABI)")
+    # torch before libbpmsm.so: the wheel brings its own HIP runtime, and a process that loaded the system one first (through
+    # the library) made torch.cuda report "No HIP GPUs are available" in the tests that move buffers with torch.  With every
+    # test file collected test_dist_gloo's import did this by accident; a subset of files (pytest tests/test_gpu_verify.py
+    # tests/test_zz_no_alloc.py) did not.  bench.py imports torch first as well.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
