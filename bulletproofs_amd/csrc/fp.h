@@ -195,6 +195,20 @@ BP_HD void fp_fold_top(fp& o, uint64_t c, uint32_t h8) {
     o.v[3] += (uint32_t)c;
 }
 
+// c + a * b as ONE v_mad_u64_u32 whose addend is the running accumulator.  Written as `c += (uint64_t)a * b` the compiler
+// reassociates every column into a chain of its own that starts at zero and adds the carried accumulator with a 64-bit addition
+// afterwards (18 v_lshl_add_u64 per multiplication, 4 issue cycles each); BP_MAD_CHAIN keeps the single chain (inline asm cannot
+// be reassociated): fewer instructions, but no instruction-level parallelism inside one multiplication.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BP_MAD_CHAIN)
+__device__ __forceinline__ uint64_t bp_mad(uint32_t a, uint32_t b, uint64_t c) {
+    uint64_t r, sc;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(sc) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#else
+BP_HD uint64_t bp_mad(uint32_t a, uint32_t b, uint64_t c) { return c + (uint64_t)a * b; }
+#endif
+
 // 9x9 product scanning on v_mad_u64_u32.  The HIGH columns 9..16 are accumulated first and split
 // into 29-bit limbs H[k] (they must become multiplier operands).  2^261 = 256 * 2^29 + 31264 (mod p),
 // so H[k] (weight 2^261 * 2^(29k)) adds 31264*H[k] to column k and 256*H[k] to column k+1: each LOW
@@ -216,7 +230,7 @@ BP_HD_MUL fp fp_mul(fp a, fp b) {
 #pragma unroll
     for (int k = 9; k < 17; k++) {
 #pragma unroll
-        for (int i = k - 8; i <= 8; i++) c += (uint64_t)a.v[i] * b.v[k - i];
+        for (int i = k - 8; i <= 8; i++) c = bp_mad(a.v[i], b.v[k - i], c);
         H[k - 9] = (uint32_t)c & BP_M29;
         c >>= 29;
     }
@@ -226,9 +240,9 @@ BP_HD_MUL fp fp_mul(fp a, fp b) {
 #pragma unroll
     for (int k = 0; k < 9; k++) {
 #pragma unroll
-        for (int i = 0; i <= k; i++) c += (uint64_t)a.v[i] * b.v[k - i];
-        c += (uint64_t)H[k] * 31264u;
-        if (k > 0) c += (uint64_t)H[k - 1] * k256;
+        for (int i = 0; i <= k; i++) c = bp_mad(a.v[i], b.v[k - i], c);
+        c = bp_mad(H[k], 31264u, c);
+        if (k > 0) c = bp_mad(H[k - 1], k256, c);
         o.v[k] = (uint32_t)c & BP_M29;
         c >>= 29;
     }
@@ -251,8 +265,8 @@ BP_HD_MUL fp fp_sqr(fp a) {
 #pragma unroll
     for (int k = 9; k < 17; k++) {
 #pragma unroll
-        for (int i = k - 8; 2 * i < k; i++) c += (uint64_t)d[i] * a.v[k - i];
-        if ((k & 1) == 0) c += (uint64_t)a.v[k / 2] * a.v[k / 2];
+        for (int i = k - 8; 2 * i < k; i++) c = bp_mad(d[i], a.v[k - i], c);
+        if ((k & 1) == 0) c = bp_mad(a.v[k / 2], a.v[k / 2], c);
         H[k - 9] = (uint32_t)c & BP_M29;
         c >>= 29;
     }
@@ -262,10 +276,10 @@ BP_HD_MUL fp fp_sqr(fp a) {
 #pragma unroll
     for (int k = 0; k < 9; k++) {
 #pragma unroll
-        for (int i = 0; 2 * i < k; i++) c += (uint64_t)d[i] * a.v[k - i];
-        if ((k & 1) == 0) c += (uint64_t)a.v[k / 2] * a.v[k / 2];
-        c += (uint64_t)H[k] * 31264u;
-        if (k > 0) c += (uint64_t)H[k - 1] * k256;
+        for (int i = 0; 2 * i < k; i++) c = bp_mad(d[i], a.v[k - i], c);
+        if ((k & 1) == 0) c = bp_mad(a.v[k / 2], a.v[k / 2], c);
+        c = bp_mad(H[k], 31264u, c);
+        if (k > 0) c = bp_mad(H[k - 1], k256, c);
         o.v[k] = (uint32_t)c & BP_M29;
         c >>= 29;
     }
