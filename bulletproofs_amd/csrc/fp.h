@@ -148,7 +148,14 @@ BP_HD fp fp_canon(const fp& a) {
     return r;
 }
 
+// Zero test.  A value is < 2^256 + 2^45 < 2p, so it is 0 mod p only as 0 or p itself, and its low 29 bits are the low 29
+// bits of limb 0 whatever slack the other limbs carry (limbs are non-negative): unless those are 0 or p mod 2^29 the value
+// is not zero and the canonicalisation (about a hundred instructions) is skipped.  xyzz_madd / xyzz_add ask this once per
+// addition (is the addend +-the accumulator?), where the answer is "no" except with probability 2^-28.
+#define BP_P_LOW29 0x1FFFFC2Fu
 BP_HD bool fp_is_zero(const fp& a) {
+    const uint32_t l0 = a.v[0] & BP_M29;
+    if (l0 != 0u && l0 != BP_P_LOW29) return false;
     fp c = fp_canon(a);
     uint32_t o = 0;
 #pragma unroll

@@ -20,6 +20,22 @@ void bpt_fp_sub(uint8_t* out, const uint8_t* a, const uint8_t* b) { fp_to_be(out
 void bpt_fp_inv(uint8_t* out, const uint8_t* a) { fp_to_be(out, fp_inv(fp_from_be(a))); }
 void bpt_fp_inv_var(uint8_t* out, const uint8_t* a) { fp_to_be(out, fp_inv_var(fp_from_be(a))); }
 void bpt_fp_sqrt(uint8_t* out, const uint8_t* a) { fp_to_be(out, fp_sqrt_candidate(fp_from_be(a))); }
+// zero tests: of raw (possibly slack) limbs, and of the lazily normalised values the point formulas ask about
+int bpt_fp_is_zero_limbs(const uint32_t* limbs) {
+    fp a;
+    for (int i = 0; i < 9; i++) a.v[i] = limbs[i];
+    return fp_is_zero(a) ? 1 : 0;
+}
+// bit 0: a - b == 0, bit 1: a*b - b*a == 0, bit 2: (a + b) - b - a == 0, bit 3: fp_eq(a, b)
+int bpt_fp_zero_forms(const uint8_t* a, const uint8_t* b) {
+    fp x = fp_from_be(a), y = fp_from_be(b);
+    int r = 0;
+    if (fp_is_zero(fp_sub(x, y))) r |= 1;
+    if (fp_is_zero(fp_sub(fp_mul(x, y), fp_mul(y, x)))) r |= 2;
+    if (fp_is_zero(fp_sub(fp_sub(fp_add(x, y), y), x))) r |= 4;
+    if (fp_eq(x, y)) r |= 8;
+    return r;
+}
 
 static fq fq_from_be_raw(const uint8_t* b) { return fq_from_be_reduce(b); }
 void bpt_fq_mul(uint8_t* out, const uint8_t* a, const uint8_t* b) { fq_to_be(out, fq_mul(fq_from_be_raw(a), fq_from_be_raw(b))); }

@@ -54,6 +54,47 @@ def test_fp(L):
         assert call1(L.bpt_fp_sqrt, a) == pow(a, (P + 1) // 4, P)
 
 
+def test_fp_is_zero_prefilter(L):
+    """fp_is_zero answers from limb 0's low 29 bits unless they are those of 0 or p: exact on slack limb forms of 0 and p, on
+    values that share p's or 0's low bits, and on the differences the point formulas test."""
+    import ctypes
+    rng = random.Random(11)
+    M = (1 << 29) - 1
+
+    def limbs_of(v):
+        return [(v >> (29 * i)) & M for i in range(8)] + [v >> 232]
+
+    def call(l):
+        return L.bpt_fp_is_zero_limbs((ctypes.c_uint32 * 9)(*l))
+
+    assert call(limbs_of(0)) == 1 and call(limbs_of(P)) == 1
+    # slack forms of p and 0: move a carry between neighbouring limbs (value unchanged, limbs stay below 2^32)
+    for base in (P, 0):
+        for _ in range(200):
+            l = limbs_of(base)
+            for _ in range(rng.randrange(1, 4)):
+                i = rng.randrange(1, 8)
+                if l[i + 1] >= 1 and l[i] + (1 << 29) < (1 << 32):
+                    l[i + 1] -= 1
+                    l[i] += 1 << 29
+            assert sum(x << (29 * i) for i, x in enumerate(l)) == base
+            assert call(l) == 1, l
+    # non-zero values whose low 29 bits are those of p or of 0
+    for low in (P & M, 0):
+        for _ in range(300):
+            v = (rng.randrange(1, 1 << 227) << 29) | low
+            if v % P:
+                assert call(limbs_of(v % (1 << 256))) == (1 if (v % (1 << 256)) % P == 0 else 0)
+    for _ in range(300):
+        assert call(limbs_of(rng.randrange(1, P))) == 0
+    # differences as xyzz_madd / xyzz_add form them
+    for _ in range(300):
+        a = rng.randrange(P)
+        assert L.bpt_fp_zero_forms(b32(a), b32(a)) == 15
+        b = (a + rng.choice([1, P - 1, 1 << 29, P - (1 << 29), rng.randrange(1, P)])) % P
+        assert L.bpt_fp_zero_forms(b32(a), b32(b)) == 6  # a != b; the two identities still hold
+
+
 def test_fp_inv_var(L):
     """fp_inv_var (Bernstein-Yang division steps, used by the single-lane tails of every MSM) against Python's pow and
     the Fermat chain: edge values, sparse values, small values, values near p, 20000 random ones."""
