@@ -149,34 +149,41 @@ BP_HD xyzz xyzz_dbl_affine(const affine& p) {
     return r;
 }
 
-// acc += p (p affine): madd-2008-s, 8M + 2S.
-BP_HD void xyzz_madd(xyzz& acc, const affine& p) {
+// acc += (neg ? -p : p) (p affine): madd-2008-s, 8M + 2S.  The sign goes into the multiplication by ZZZ as a lazy operand
+// (nine subtractions and selects instead of a normalised negation behind a branch), X3 = R^2 - PPP - 2Q is one
+// normalisation instead of three and Q - X3 none (fp.h, "linear combinations"): four normalisations per addition, not seven.
+BP_HD void xyzz_madd_s(xyzz& acc, const affine& p, bool neg) {
     if (affine_is_inf(p)) return;
     if (xyzz_is_inf(acc)) {
         acc = xyzz_from_affine(p);
+        if (neg) acc.Y = fp_neg(acc.Y);
         return;
     }
     fp U2 = fp_mul(p.x, acc.ZZ);
-    fp S2 = fp_mul(p.y, acc.ZZZ);
+    fp S2 = fp_mul(fp_cneg_lazy(p.y, neg), acc.ZZZ);
     fp Pd = fp_sub(U2, acc.X);
     fp R = fp_sub(S2, acc.Y);
     if (fp_is_zero(Pd)) {
-        if (fp_is_zero(R))
-            acc = xyzz_dbl_affine(p);
-        else
+        if (fp_is_zero(R)) {
+            affine q = p;
+            if (neg) q.y = fp_neg(p.y);
+            acc = xyzz_dbl_affine(q);
+        } else {
             acc = xyzz_inf();
+        }
         return;
     }
     fp PP = fp_sqr(Pd);
     fp PPP = fp_mul(Pd, PP);
     fp Qv = fp_mul(acc.X, PP);
-    fp X3 = fp_sub(fp_sub(fp_sqr(R), PPP), fp_dbl(Qv));
-    fp Y3 = fp_sub(fp_mul(R, fp_sub(Qv, X3)), fp_mul(acc.Y, PPP));
+    fp X3 = fp_sub_b_2c(fp_sqr(R), PPP, Qv);
+    fp Y3 = fp_sub(fp_mul(R, fp_sub_lazy(Qv, X3)), fp_mul(acc.Y, PPP));
     acc.X = X3;
     acc.Y = Y3;
     acc.ZZ = fp_mul(acc.ZZ, PP);
     acc.ZZZ = fp_mul(acc.ZZZ, PPP);
 }
+BP_HD void xyzz_madd(xyzz& acc, const affine& p) { xyzz_madd_s(acc, p, false); }
 
 // acc += q (both XYZZ): add-2008-s, 12M + 2S.
 BP_HD void xyzz_add(xyzz& acc, const xyzz& q) {
@@ -201,8 +208,8 @@ BP_HD void xyzz_add(xyzz& acc, const xyzz& q) {
     fp PP = fp_sqr(Pd);
     fp PPP = fp_mul(Pd, PP);
     fp Qv = fp_mul(U1, PP);
-    fp X3 = fp_sub(fp_sub(fp_sqr(R), PPP), fp_dbl(Qv));
-    fp Y3 = fp_sub(fp_mul(R, fp_sub(Qv, X3)), fp_mul(S1, PPP));
+    fp X3 = fp_sub_b_2c(fp_sqr(R), PPP, Qv);
+    fp Y3 = fp_sub(fp_mul(R, fp_sub_lazy(Qv, X3)), fp_mul(S1, PPP));
     acc.X = X3;
     acc.Y = Y3;
     acc.ZZ = fp_mul(fp_mul(acc.ZZ, q.ZZ), PP);
@@ -221,17 +228,17 @@ BP_HD xyzz xyzz_dbl_n(const xyzz& p, int k) {
         return r;
     }
     fp X = fp_mul(p.X, p.ZZ), Y = fp_mul(p.Y, p.ZZZ), Z = p.ZZ;
+    // dbl-2009-l with the linear steps merged (fp.h, "linear combinations"): six normalisations per doubling instead of
+    // fourteen.  H = (X + B)^2 - A - C = D / 2.
     for (int i = 0; i < k; i++) {
         fp A = fp_sqr(X);
         fp B = fp_sqr(Y);
         fp C = fp_sqr(B);
-        fp t = fp_add(X, B);
-        fp D = fp_dbl(fp_sub(fp_sub(fp_sqr(t), A), C));
-        fp E = fp_add(fp_dbl(A), A);
-        fp F = fp_sqr(E);
-        fp Z3 = fp_dbl(fp_mul(Y, Z));
-        X = fp_sub(F, fp_dbl(D));
-        Y = fp_sub(fp_mul(E, fp_sub(D, X)), fp_dbl(fp_dbl(fp_dbl(C))));
+        fp H = fp_sub2(fp_sqr(fp_add(X, B)), A, C);
+        fp E = fp_mul3(A);
+        fp Z3 = fp_mul(fp_dbl_lazy(Y), Z);
+        X = fp_sub_4b(fp_sqr(E), H);                                              // F - 2D
+        Y = fp_sub_2b(fp_mul(E, fp_2a_sub_lazy(H, X)), fp_mul4(C));               // E (D - X3) - 8C
         Z = Z3;
     }
     xyzz r;

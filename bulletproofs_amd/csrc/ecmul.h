@@ -225,8 +225,7 @@ BP_HD xyzz ec_mul_glv_multi(LoadP loadP, LoadK loadK, int cnt, xyzz* tab, affine
             B = fetch(d1, t + 1);
             if (d0 != 0) {
                 affine e = affine_load(A);
-                if (d0 < 0) e.y = fp_neg(e.y);
-                xyzz_madd(acc, e);
+                xyzz_madd_s(acc, e, d0 < 0);
             }
             const bool more = t + 2 < nt;
             d0 = more ? digit_of(dcur, t + 2) : digit_of(dnext, 0);  // w == 0: dnext is stale, the entry is never used
@@ -234,8 +233,7 @@ BP_HD xyzz ec_mul_glv_multi(LoadP loadP, LoadK loadK, int cnt, xyzz* tab, affine
             if (d1 != 0) {
                 affine e = affine_load(B);
                 e.x = fp_mul(e.x, beta);
-                if (d1 < 0) e.y = fp_neg(e.y);
-                xyzz_madd(acc, e);
+                xyzz_madd_s(acc, e, d1 < 0);
             }
         }
         for (int i = 0; i < (DW + 3) / 4; i++) dcur[i] = dnext[i];

@@ -54,8 +54,7 @@ __global__ __launch_bounds__(FB_T) void k_fb_acc(const affine_mem* __restrict__ 
             int d = dig[(size_t)t * W + w];
             if (d != 0) {
                 affine e = affine_load(table[((size_t)gidx[t] * W + w) * NB + ((d < 0 ? -d : d) - 1)]);
-                if (d < 0) e.y = fp_neg(e.y);
-                xyzz_madd(acc, e);
+                xyzz_madd_s(acc, e, d < 0);
             }
         }
     } else {

@@ -81,6 +81,9 @@ static __device__ unsigned int bp_oc_mul[BP_OPCOUNT_SLOTS], bp_oc_sqr[BP_OPCOUNT
 #define BP_OPCOUNT_READER(name)
 #endif
 
+#if defined(BP_CHECK_BOUNDS) && !defined(__HIPCC__)
+#include <stdlib.h>  // abort() of the bounds-checking host build
+#endif
 namespace bp {
 
 struct fp {
@@ -90,6 +93,15 @@ struct fp_words {  // canonical value < p as 8 little-endian 32-bit words (memor
     uint32_t w[8];
 };
 
+#if defined(BP_CHECK_BOUNDS) && !defined(__HIPCC__)
+#define BP_LIMB(expr) bp_limb_checked((int64_t)(expr))
+inline uint32_t bp_limb_checked(int64_t v) {
+    if (v < 0 || v > 0xFFFFFFFFll) abort();
+    return (uint32_t)v;
+}
+#else
+#define BP_LIMB(expr) ((uint32_t)(expr))
+#endif
 #define BP_M29 0x1FFFFFFFu
 #define BP_P_C0 977u  // 2^256 - p = 2^32 + 977 = 977 + 8 * 2^29
 
@@ -176,11 +188,104 @@ BP_HD fp fp_sub(const fp& a, const fp& b) {
     const uint32_t K[9] = {0x5ffff0bcu, 0x5fffffddu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x03fffffdu};
     fp r;
 #pragma unroll
-    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + K[i] - b.v[i];
+    for (int i = 0; i < 9; i++) r.v[i] = BP_LIMB((int64_t)a.v[i] + K[i] - b.v[i]);
     fp_normalize(r.v);
     return r;
 }
 BP_HD fp fp_neg(const fp& a) { return fp_sub(fp_zero(), a); }
+
+// ---- linear combinations with ONE normalisation, and operands that skip it ------------------------------------------
+// fp_add / fp_sub normalise after every operation (~30 instructions, as many as the operation itself); the point formulas
+// chain several of them, and every instruction costs a multiply's issue slot (profiles/r02_fp_variants.txt).  The helpers
+// below form  m_a a - m_b b - m_c c + (K or 2K)  limb by limb and normalise once.  Inputs are normalised values (limbs
+// <= 2^29 + 2^13, limb 8 < 2^24).  Bounds: K = 4p has limbs >= 1.5 * 2^30 - 3 (limb 8: 2^26 - 3), 2K = 8p twice that, so
+//   with K :  m_b + m_c <= 2  and  m_a <= 4   (m_a 2^29 + 1.5 * 2^30 < 2^32)
+//   with 2K:  m_b + m_c <= 5  and  m_a <= 1   (2^29 + 3 * 2^30 < 2^32)
+// keep every limb in [0, 2^32); fp_normalize's carries (<= 7) and its single fold of the top (value < 10 p) restore the invariant.
+#define BP_K4P {0x5ffff0bcu, 0x5fffffddu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x03fffffdu}
+#define BP_K8P {0xbfffe178u, 0xbfffffbau, 0xbffffffau, 0xbffffffau, 0xbffffffau, 0xbffffffau, 0xbffffffau, 0xbffffffau, 0x07fffffau}
+// a - b - c
+BP_HD fp fp_sub2(const fp& a, const fp& b, const fp& c) {
+    const uint32_t K[9] = BP_K4P;
+    fp r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = BP_LIMB((int64_t)a.v[i] + K[i] - b.v[i] - c.v[i]);
+    fp_normalize(r.v);
+    return r;
+}
+// a - b - 2c   (X3 of the additions: R^2 - PPP - 2Q)
+BP_HD fp fp_sub_b_2c(const fp& a, const fp& b, const fp& c) {
+    const uint32_t K[9] = BP_K8P;
+    fp r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = BP_LIMB((int64_t)a.v[i] + K[i] - b.v[i] - 2 * (int64_t)c.v[i]);
+    fp_normalize(r.v);
+    return r;
+}
+// a - 2b
+BP_HD fp fp_sub_2b(const fp& a, const fp& b) {
+    const uint32_t K[9] = BP_K4P;
+    fp r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = BP_LIMB((int64_t)a.v[i] + K[i] - 2 * (int64_t)b.v[i]);
+    fp_normalize(r.v);
+    return r;
+}
+// a - 4b
+BP_HD fp fp_sub_4b(const fp& a, const fp& b) {
+    const uint32_t K[9] = BP_K8P;
+    fp r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = BP_LIMB((int64_t)a.v[i] + K[i] - 4 * (int64_t)b.v[i]);
+    fp_normalize(r.v);
+    return r;
+}
+// 3a, 4a
+BP_HD fp fp_mul3(const fp& a) {
+    fp r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = BP_LIMB(3 * (int64_t)a.v[i]);
+    fp_normalize(r.v);
+    return r;
+}
+BP_HD fp fp_mul4(const fp& a) {
+    fp r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = BP_LIMB(4 * (int64_t)a.v[i]);
+    fp_normalize(r.v);
+    return r;
+}
+// LAZY results: not normalised (limbs < 2^31.4, value a multiple of p off), valid ONLY as one operand of fp_mul whose other
+// operand is normalised: a column of nine products stays below 9 * 2^31.4 * 2^29.001 < 2^63.6.  Never into fp_sqr, fp_add,
+// fp_sub, fp_is_zero or memory.
+BP_HD fp fp_sub_lazy(const fp& a, const fp& b) {  // a - b
+    const uint32_t K[9] = BP_K4P;
+    fp r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = BP_LIMB((int64_t)a.v[i] + K[i] - b.v[i]);
+    return r;
+}
+BP_HD fp fp_2a_sub_lazy(const fp& a, const fp& b) {  // 2a - b
+    const uint32_t K[9] = BP_K4P;
+    fp r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = BP_LIMB(2 * (int64_t)a.v[i] + K[i] - b.v[i]);
+    return r;
+}
+BP_HD fp fp_dbl_lazy(const fp& a) {  // 2a
+    fp r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = BP_LIMB(2 * (int64_t)a.v[i]);
+    return r;
+}
+BP_HD fp fp_cneg_lazy(const fp& a, bool neg) {  // neg ? -a : a, without a branch
+    const uint32_t K[9] = BP_K4P;
+    fp r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = neg ? BP_LIMB((int64_t)K[i] - a.v[i]) : a.v[i];
+    return r;
+}
+
 BP_HD fp fp_dbl(const fp& a) { return fp_add(a, a); }
 BP_HD bool fp_eq(const fp& a, const fp& b) { return fp_is_zero(fp_sub(a, b)); }
 
@@ -210,6 +315,13 @@ BP_HD void fp_fold_top(fp& o, uint64_t c, uint32_t h8) {
 __device__ __forceinline__ uint64_t bp_mad(uint32_t a, uint32_t b, uint64_t c) {
     uint64_t r, sc;
     asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(sc) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#elif defined(BP_CHECK_BOUNDS) && !defined(__HIPCC__)
+// host build of the sanitizer tests: a column accumulator that wraps or a limb that leaves [0, 2^32) aborts
+inline uint64_t bp_mad(uint32_t a, uint32_t b, uint64_t c) {
+    uint64_t r;
+    if (__builtin_add_overflow(c, (uint64_t)a * b, &r)) abort();
     return r;
 }
 #else

@@ -20,6 +20,29 @@ void bpt_fp_sub(uint8_t* out, const uint8_t* a, const uint8_t* b) { fp_to_be(out
 void bpt_fp_inv(uint8_t* out, const uint8_t* a) { fp_to_be(out, fp_inv(fp_from_be(a))); }
 void bpt_fp_inv_var(uint8_t* out, const uint8_t* a) { fp_to_be(out, fp_inv_var(fp_from_be(a))); }
 void bpt_fp_sqrt(uint8_t* out, const uint8_t* a) { fp_to_be(out, fp_sqrt_candidate(fp_from_be(a))); }
+// linear combinations with one normalisation and the lazy operands (fp.h); inputs are first passed through a multiplication and
+// an addition so that they are normalised-but-not-canonical values as the point formulas see them: x = a*b + c, y = b*c + a,
+// z = c*a + b.  op: 0 x-y-z, 1 x-y-2z, 2 x-2y, 3 x-4y, 4 3x, 5 4x, 6 (x-y)*z lazy, 7 (2x-y)*z lazy, 8 (2x)*z lazy,
+// 9 (-x)*z lazy, 10 (+x)*z lazy
+void bpt_fp_lin(uint8_t* out, const uint8_t* a, const uint8_t* b, const uint8_t* c, int op) {
+    fp A = fp_from_be(a), B = fp_from_be(b), C = fp_from_be(c);
+    fp x = fp_add(fp_mul(A, B), C), y = fp_add(fp_mul(B, C), A), z = fp_add(fp_mul(C, A), B);
+    fp r = fp_zero();
+    switch (op) {
+        case 0: r = fp_sub2(x, y, z); break;
+        case 1: r = fp_sub_b_2c(x, y, z); break;
+        case 2: r = fp_sub_2b(x, y); break;
+        case 3: r = fp_sub_4b(x, y); break;
+        case 4: r = fp_mul3(x); break;
+        case 5: r = fp_mul4(x); break;
+        case 6: r = fp_mul(fp_sub_lazy(x, y), z); break;
+        case 7: r = fp_mul(z, fp_2a_sub_lazy(x, y)); break;
+        case 8: r = fp_mul(fp_dbl_lazy(x), z); break;
+        case 9: r = fp_mul(fp_cneg_lazy(x, true), z); break;
+        case 10: r = fp_mul(z, fp_cneg_lazy(x, false)); break;
+    }
+    fp_to_be(out, r);
+}
 // zero tests: of raw (possibly slack) limbs, and of the lazily normalised values the point formulas ask about
 int bpt_fp_is_zero_limbs(const uint32_t* limbs) {
     fp a;

@@ -34,6 +34,19 @@ int main() {
     uint8_t a[32], b[32], c[32], d[32], e[32], one[32] = {0};
     one[31] = 1;
     expect(bpt_ec_on_curve(G) == 1, "G on curve");
+    // one-normalisation linear combinations and lazy multiplier operands, limb ranges and column sums checked (BP_CHECK_BOUNDS):
+    // all-ones patterns drive every limb to its maximum
+    for (int it = 0; it < 2000; it++) {
+        uint8_t x[32], y[32], z[32], o[32];
+        rnd32(x, false);
+        rnd32(y, false);
+        rnd32(z, false);
+        if (it % 7 == 0) memset(x, 0xFF, 32);
+        if (it % 11 == 0) memset(y, 0xFF, 32);
+        if (it % 13 == 0) memset(z, 0xFF, 32);
+        if (it % 17 == 0) memset(y, 0, 32);
+        for (int op = 0; op <= 10; op++) bpt_fp_lin(o, x, y, z, op);
+    }
     for (int it = 0; it < 300; it++) {
         rnd32(a, true);
         rnd32(b, true);

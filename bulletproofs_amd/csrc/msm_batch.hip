@@ -76,8 +76,7 @@ __global__ __launch_bounds__(256, 2) void k_mb_msm(size_t njobs, int np, const a
                 int d = dg[idx];
                 if (d != 0) {
                     affine e = affine_load(table[(size_t)idx * NB + ((d < 0 ? -d : d) - 1)]);
-                    if (d < 0) e.y = fp_neg(e.y);
-                    xyzz_madd(acc, e);
+                    xyzz_madd_s(acc, e, d < 0);
                 }
             }
         }

@@ -199,8 +199,7 @@ __global__ __launch_bounds__(256, 2) void k_srt_acc(const affine_mem* __restrict
             cur = b;
             atstart = false;
         }
-        if (ec.x >> 31) p.y = fp_neg(p.y);
-        xyzz_madd(acc, p);
+        xyzz_madd_s(acc, p, ec.x >> 31);
     }
     if (atstart)
         Pseg[(size_t)w * pstride + t] = acc;

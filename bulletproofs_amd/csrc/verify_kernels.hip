@@ -131,8 +131,7 @@ __global__ __launch_bounds__(256, BPV_FIX_WAVES) void k_bpv_fix(int nm, size_t n
         auto add = [&](const affine_mem& m, int d, int idx) {
             if (d != 0 && idx < nfw) {
                 affine e = affine_load(m);
-                if (d < 0) e.y = fp_neg(e.y);
-                xyzz_madd(acc, e);
+                xyzz_madd_s(acc, e, d < 0);
             }
         };
         int dA = digit(lane), dB = digit(lane + TP);

@@ -233,8 +233,7 @@ __global__ __launch_bounds__(256) void k_bpv_fixmul(int k, int nm, size_t nproof
             int d = window_digit(s, c, w, carry);
             if ((w % FM_SUB) == sub && d != 0) {
                 affine e = affine_load(table[(pG * W + w) * NB + ((d < 0 ? -d : d) - 1)]);
-                if (d < 0) e.y = fp_neg(e.y);
-                xyzz_madd(acc, e);
+                xyzz_madd_s(acc, e, d < 0);
             }
         }
     }

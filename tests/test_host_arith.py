@@ -54,6 +54,24 @@ def test_fp(L):
         assert call1(L.bpt_fp_sqrt, a) == pow(a, (P + 1) // 4, P)
 
 
+def test_fp_linear_combinations_and_lazy_operands(L):
+    """fp.h's one-normalisation linear combinations and the lazy (unnormalised) multiplier operands, on extreme and random inputs."""
+    rng = random.Random(13)
+    edge = [0, 1, P - 1, P - 2, 2**255, P - 2**32 - 977, (1 << 256) - 1 - (1 << 32), 2**32 + 977, (1 << 232) - 1, P >> 1]
+    vals = edge + [rng.randrange(P) for _ in range(60)]
+    want = [lambda x, y, z: x - y - z, lambda x, y, z: x - y - 2 * z, lambda x, y, z: x - 2 * y, lambda x, y, z: x - 4 * y,
+            lambda x, y, z: 3 * x, lambda x, y, z: 4 * x, lambda x, y, z: (x - y) * z, lambda x, y, z: (2 * x - y) * z,
+            lambda x, y, z: 2 * x * z, lambda x, y, z: -x * z, lambda x, y, z: x * z]
+    for a in vals:
+        for _ in range(6):
+            b, c = rng.choice(vals), rng.choice(vals)
+            x, y, z = (a * b + c) % P, (b * c + a) % P, (c * a + b) % P
+            for op, f in enumerate(want):
+                o = ctypes.create_string_buffer(32)
+                L.bpt_fp_lin(o, b32(a % (1 << 256)), b32(b), b32(c), op)
+                assert int.from_bytes(o.raw, "big") == f(x, y, z) % P, (op, a, b, c)
+
+
 def test_fp_is_zero_prefilter(L):
     """fp_is_zero answers from limb 0's low 29 bits unless they are those of 0 or p: exact on slack limb forms of 0 and p, on
     values that share p's or 0's low bits, and on the differences the point formulas test."""
