@@ -48,12 +48,12 @@ EXEC_MAD32_PER_PROOF_MSM = 2.907e6
 EXEC_MAD32_PER_POINT_MSM = 18578.0
 # HBM-side traffic of one verification MSM (the launch pair k_bpv_fix + k_bpv_msm) at the default configuration (65536
 # distinct proofs, auto lanes, 20-bit table windows), from the separate --pmc passes in profiles/r02_pmc_read.csv /
-# r02_pmc_write.csv:  k_bpv_fix TCC_EA0_RDREQ 75.37e6 x 64 B (the 1690 table gathers per proof are 110.8e6 lines: a third
-# hit in L2) + 0.15e6 x 64 B written;  k_bpv_msm RDREQ 88.88e6 x 64 B + WRREQ 39.38e6 x 64 B + 18.29e6 x 32 B (the
+# r02_pmc_write.csv:  k_bpv_fix TCC_EA0_RDREQ 74.48e6 x 64 B (the 1690 table gathers per proof are 110.8e6 lines: a third
+# hit in L2) + 0.15e6 x 64 B written;  k_bpv_msm RDREQ 90.10e6 x 64 B + WRREQ 40.34e6 x 64 B + 17.85e6 x 32 B (the
 # lane-private window tables of the proof-specific points, built in and re-read from global scratch).  64-byte gathers, not
 # the 16-B/lane streaming pattern the guide's x2 correction was calibrated on: RDREQ x 64 B already matches the algorithmic
-# gather bytes, so no doubling.  13.6 GB in 14.2 ms = 0.96 TB/s, 12 % of the HBM peak: the kernels are VALU-bound.
-PMC_TRAFFIC_BYTES_DEFAULT = (75.37e6 + 88.88e6) * 64 + 0.15e6 * 64 + 39.38e6 * 64 + 18.29e6 * 32
+# gather bytes, so no doubling.  13.7 GB in 12.9 ms = 1.06 TB/s, 13 % of the HBM peak: the kernels are VALU-bound.
+PMC_TRAFFIC_BYTES_DEFAULT = (74.48e6 + 90.10e6) * 64 + 0.15e6 * 64 + 40.34e6 * 64 + 17.85e6 * 32
 
 
 # Rehearsal of the multi-rank path on a ONE-GPU box (BENCH_REHEARSAL=1 under torch.distributed.run): every rank uses
