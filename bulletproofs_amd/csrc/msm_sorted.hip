@@ -298,10 +298,13 @@ __global__ __launch_bounds__(64) void k_srt_dbl(xyzz* __restrict__ wsum, int idx
 // A row's segments are one contiguous range; a column gives each of its HI buckets T/HI lanes (at least one), and buckets
 // with many segments (the short top window, skewed scalars) are summed by the whole workgroup afterwards.
 // Depth: ~2-3 additions per lane + an 8-level LDS tree, whatever the bucket sizes are.
+// LDS: blockDim.x XYZZ slots, passed as dynamic shared memory (a 64-lane launch then takes 9 KB, not the 36 KB of 256 lanes:
+// with a fixed red[256] only four workgroups fitted a CU and the 64-lane form ran at one wave per SIMD).
 __global__ __launch_bounds__(256) void k_srt_rowcol2(const uint32_t* __restrict__ bstart, const xyzz* __restrict__ Bk,
                                                         const xyzz* __restrict__ Pseg, int NB, int L, int pstride, int lo_bits, int w0,
                                                         xyzz* __restrict__ RC) {
-    __shared__ xyzz red[256];
+    extern __shared__ __align__(16) unsigned char srt_rc_lds[];
+    xyzz* red = reinterpret_cast<xyzz*>(srt_rc_lds);
     __builtin_amdgcn_s_setprio(3);  // latency-bound: issue ahead of the co-resident accumulation waves
     __shared__ uint32_t big_t0[256], big_t1[256];
     __shared__ uint32_t nbig;
@@ -410,7 +413,7 @@ static hipError_t srt_reduce_windows(const SortedPlan& pl, const SortedBufs& b, 
     // costs more than the two tree levels it saves; gpurun sweep of BP_MSM_RC_T)
     int T = 256;
     if (const char* e = getenv("BP_MSM_RC_T")) T = atoi(e) == 64 || atoi(e) == 128 || atoi(e) == 256 ? atoi(e) : T;
-    hipLaunchKernelGGL(k_srt_rowcol2, dim3((unsigned)nout, (unsigned)nw), dim3((unsigned)T), 0, st, b.bstart, b.Bk, b.Pseg, NB, L, pl.nseg,
+    hipLaunchKernelGGL(k_srt_rowcol2, dim3((unsigned)nout, (unsigned)nw), dim3((unsigned)T), (size_t)T * sizeof(xyzz), st, b.bstart, b.Bk, b.Pseg, NB, L, pl.nseg,
                        pl.lo_bits, w0, b.RC);
     hipLaunchKernelGGL(k_srt_window, dim3((unsigned)nw), dim3(256), 0, st, b.bstart, b.RC, NB, pl.lo_bits, w0, wsum);
     return hipGetLastError();
