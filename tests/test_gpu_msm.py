@@ -156,6 +156,10 @@ def test_msm_grouped_pipeline_skewed_scalars(ctx, oracle_c):
         want_scalar = sum(ks[i] * rs[idx[i]] for i in range(n)) % ec.Q
         want = ec.enc64(oracle_c.mul(ec.G, want_scalar)) if want_scalar else bytes(64)
         assert ctx.msm(pb, sb, None) == want, name
+        if name in ("pm1", "mixed"):  # with an init point: the final kernel adds S_0, the doubled upper combination AND init
+            init = oracle_c.mul(ec.G, 0xC0FFEE)
+            want_i = (want_scalar + 0xC0FFEE) % ec.Q
+            assert ctx.msm(pb, sb, ec.enc64(init)) == (ec.enc64(oracle_c.mul(ec.G, want_i)) if want_i else bytes(64)), name
         ctx.set_msm_pipeline(1)  # one window group, no side streams (bp_msm_set_pipeline): same bytes
         try:
             assert ctx.msm(pb, sb, None) == want, name
