@@ -198,9 +198,9 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
     if (want_c) path = 2;
     const int forced_c = want_c ? want_c : ctx->forced_c;
     if ((rc = ctx->lam.reserve(n * sizeof(affine_mem))) != BP_OK) return rc;
-    HIPCHK(launch_glv_expand(d_points, (affine_mem*)ctx->lam.p, n, st), "glv expand");
     const affine_mem* lam = (const affine_mem*)ctx->lam.p;
     if (path == 1) {
+        HIPCHK(launch_glv_expand(d_points, (affine_mem*)ctx->lam.p, n, st), "glv expand");
         MsmPlan pl = plan_msm(n2, forced_c);
         *c_out = pl.c;
         *W_out = pl.W;
@@ -235,7 +235,6 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
         b.Bk = (xyzz*)ctx->srt[4].p;
         b.Pseg = (xyzz*)ctx->srt[5].p;
         b.RC = (xyzz*)ctx->srt[6].p;
-        HIPCHK(launch_glv_digits(d_scalars_be, n, pl.npad, pl.c, pl.W, (int16_t*)ctx->digits.p, st), "digits");
         // large MSMs: window groups, top-down; every group's latency-bound tail (bucket reduction, Horner chain)
         // overlaps the following groups' accumulation (not when the caller wants every raw window sum: the
         // multi-GPU partials)
@@ -256,6 +255,21 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
             }
             HIPCHK(hipEventCreateWithFlags(&ss->ev_join, hipEventDisableTiming), "hipEventCreate");
             HIPCHK(hipEventCreateWithFlags(&ss->ev_fork, hipEventDisableTiming), "hipEventCreate");
+            HIPCHK(hipEventCreateWithFlags(&ss->ev_start, hipEventDisableTiming), "hipEventCreate");
+            HIPCHK(hipEventCreateWithFlags(&ss->ev_lam, hipEventDisableTiming), "hipEventCreate");
+        }
+        if (ng > 1) {
+            // lambda * P (one field multiplication per point, 128 MB of traffic at 2^20) on a side stream beside the digit kernel
+            SortedStreams* ss = ctx->srt_streams;
+            HIPCHK(hipEventRecord(ss->ev_start, st), "hipEventRecord");
+            HIPCHK(hipStreamWaitEvent(ss->st2, ss->ev_start, 0), "hipStreamWaitEvent");
+            HIPCHK(launch_glv_expand(d_points, (affine_mem*)ctx->lam.p, n, ss->st2), "glv expand");
+            HIPCHK(hipEventRecord(ss->ev_lam, ss->st2), "hipEventRecord");
+            HIPCHK(launch_glv_digits(d_scalars_be, n, pl.npad, pl.c, pl.W, (int16_t*)ctx->digits.p, st), "digits");
+            HIPCHK(hipStreamWaitEvent(st, ss->ev_lam, 0), "hipStreamWaitEvent");
+        } else {
+            HIPCHK(launch_glv_expand(d_points, (affine_mem*)ctx->lam.p, n, st), "glv expand");
+            HIPCHK(launch_glv_digits(d_scalars_be, n, pl.npad, pl.c, pl.W, (int16_t*)ctx->digits.p, st), "digits");
         }
         pl.ncu = ctx->ncu;
         int c_eff = pl.c;
@@ -391,6 +405,8 @@ void bp_ctx_destroy(bp_ctx* ctx) {
         }
         if (ss->ev_join) (void)hipEventDestroy(ss->ev_join);
         if (ss->ev_fork) (void)hipEventDestroy(ss->ev_fork);
+        if (ss->ev_start) (void)hipEventDestroy(ss->ev_start);
+        if (ss->ev_lam) (void)hipEventDestroy(ss->ev_lam);
         delete ss;
         ctx->srt_streams = nullptr;
     }

@@ -45,7 +45,7 @@ struct SortedBufs {
 struct SortedStreams {
     static const int kMaxGroups = 8;
     hipStream_t st2, st3, st4;
-    hipEvent_t ev_acc[kMaxGroups], ev_red[kMaxGroups], ev_sorted[kMaxGroups], ev_join, ev_fork;
+    hipEvent_t ev_acc[kMaxGroups], ev_red[kMaxGroups], ev_sorted[kMaxGroups], ev_join, ev_fork, ev_start, ev_lam;
 };
 hipError_t launch_msm_sorted(const affine_mem* pts, const affine_mem* lam, size_t n1, const int16_t* digits, size_t n2, const SortedPlan& pl,
                              const SortedBufs& b, xyzz* wsum, hipStream_t st, const SortedStreams* ss, const int* gsz, int ng, int* W_eff,

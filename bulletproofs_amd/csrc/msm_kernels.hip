@@ -118,10 +118,18 @@ __global__ void k_glv_digits(const uint8_t* __restrict__ scalars_be, size_t n, s
         return;
     }
     if (i >= n) return;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(scalars_be + 32 * i);
     fq k;
+    if ((reinterpret_cast<uintptr_t>(scalars_be) & 15) == 0) {  // the usual case: two 16-byte loads per scalar instead of eight dwords
+        const uint4* q = reinterpret_cast<const uint4*>(scalars_be + 32 * i);
+        const uint4 hi = q[0], lo = q[1];
+        k.v[7] = __builtin_bswap32(hi.x), k.v[6] = __builtin_bswap32(hi.y), k.v[5] = __builtin_bswap32(hi.z), k.v[4] = __builtin_bswap32(hi.w);
+        k.v[3] = __builtin_bswap32(lo.x), k.v[2] = __builtin_bswap32(lo.y), k.v[1] = __builtin_bswap32(lo.z), k.v[0] = __builtin_bswap32(lo.w);
+    } else {
+        const uint8_t* b = scalars_be + 32 * i;
 #pragma unroll
-    for (int j = 0; j < 8; j++) k.v[j] = __builtin_bswap32(src[7 - j]);
+        for (int j = 0; j < 8; j++)
+            k.v[7 - j] = ((uint32_t)b[4 * j] << 24) | ((uint32_t)b[4 * j + 1] << 16) | ((uint32_t)b[4 * j + 2] << 8) | (uint32_t)b[4 * j + 3];
+    }
     fq_final_reduce(k.v, 0);
     fq k1, k2;
     bool n1, n2;
