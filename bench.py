@@ -102,6 +102,7 @@ def parse():
     ap.add_argument("--no-bpplus", action="store_true", help="skip the Bulletproofs+ batch side measurement")
     ap.add_argument("--no-c2", action="store_true", help="skip the n=64 m=16 batch side measurement")
     ap.add_argument("--no-msm", action="store_true", help="skip the raw 2^k-point MSM side measurement")
+    ap.add_argument("--no-overlap", action="store_true", help="bp_verify_set_overlap(ctx, 0): successive device calls one after the other (A/B)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep")
     ap.add_argument("--no-tiled", action="store_true", help="skip the tiled-batch (round 1 data shape) side measurement")
     ap.add_argument("--prove-threads", type=int, default=8, help="--workload prove: contexts in flight for the throughput figure")
@@ -614,21 +615,36 @@ def main():
     want = tamper_batch(pb, plen, P, TX_AT)
     d_proofs = torch.frombuffer(pb, dtype=torch.uint8).to(dev)
     d_coms = torch.frombuffer(bytearray(coms), dtype=torch.uint8).to(dev)
-    d_verdicts = torch.full((P,), 77, dtype=torch.uint8, device=dev)
+    # Successive device calls of one context overlap (bp_verify_set_overlap: two batches in flight), so every call in
+    # flight gets a verdict buffer of its own.
+    d_verd = [torch.full((P,), 77, dtype=torch.uint8, device=dev) for _ in range(2)]
+    calls = [0]
+    if args.no_overlap:
+        ctx.set_verify_overlap(0)
     torch.cuda.synchronize()
 
     def run(count, dp=d_proofs, dc=d_coms):
-        ctx.rangeproof_verify_batch_device(gens, 64, 1, dp.data_ptr(), plen, dc.data_ptr(), count, d_verdicts.data_ptr())
+        dv = d_verd[calls[0] & 1]
+        calls[0] += 1
+        ctx.rangeproof_verify_batch_device(gens, 64, 1, dp.data_ptr(), plen, dc.data_ptr(), count, dv.data_ptr())
+
+    def check(count, what, dp=d_proofs, dc=d_coms):
+        for dv in d_verd:
+            dv.fill_(77)
+        torch.cuda.synchronize()
+        run(count, dp, dc)
+        run(count, dp, dc)
+        ctx.sync()
+        for dv in d_verd:
+            if bytes(dv[:count].cpu().numpy().tobytes()) != bytes(want[:count]) and not args.skip_check:
+                raise SystemExit("%s: verdict mismatch on rank %d" % (what, rank))
 
     def step():
         run(P)
 
     for _ in range(args.warmup):
         step()
-    ctx.sync()
-    got = bytes(d_verdicts.cpu().numpy().tobytes())
-    if got != bytes(want) and not args.skip_check:
-        raise SystemExit("verdict mismatch on rank %d" % rank)
+    check(P, "headline batch")
 
     def barrier():
         if world > 1:
@@ -675,11 +691,7 @@ def main():
         for count in (512, 4096, 16384, 65536):
             if count > P:
                 continue
-            d_verdicts.fill_(77)
-            run(count)
-            ctx.sync()
-            if bytes(d_verdicts[:count].cpu().numpy().tobytes()) != bytes(want[:count]) and not args.skip_check:
-                raise SystemExit("sweep: verdict mismatch at %d proofs" % count)
+            check(count, "sweep at %d proofs" % count)
             reps = max(args.steps, 20 if count <= 4096 else args.steps)
             barrier()
             t0 = time.perf_counter()
@@ -688,7 +700,16 @@ def main():
             ctx.sync()
             barrier()
             dts = max_over_ranks(time.perf_counter() - t0)
-            sweep.append({"proofs_per_launch_per_gpu": count, "ms_per_launch": dts / reps * 1e3, "proofs_per_s": world * count * reps / dts})
+            # the same launches one at a time (a sync after each): the latency of one batch, no overlap between calls
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                run(count)
+                ctx.sync()
+            barrier()
+            dtl = max_over_ranks(time.perf_counter() - t0)
+            sweep.append({"proofs_per_launch_per_gpu": count, "ms_per_launch": dts / reps * 1e3, "proofs_per_s": world * count * reps / dts,
+                          "ms_one_call_at_a_time": dtl / reps * 1e3})
 
     # the round-1 data shape, once, for the record: 256 distinct golden proofs tiled to the batch
     tiled = None
@@ -700,10 +721,7 @@ def main():
         tamper_batch(tb, plen, P, TX_AT)
         d_tp = torch.frombuffer(tb, dtype=torch.uint8).to(dev)
         d_tc = torch.frombuffer(bytearray((gc * reps_t)[:P * 64]), dtype=torch.uint8).to(dev)
-        run(P, d_tp, d_tc)
-        ctx.sync()
-        if bytes(d_verdicts.cpu().numpy().tobytes()) != bytes(want) and not args.skip_check:
-            raise SystemExit("tiled batch: verdict mismatch")
+        check(P, "tiled batch", d_tp, d_tc)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -775,16 +793,21 @@ def main():
         d_p2 = torch.frombuffer(pb2, dtype=torch.uint8).to(dev)
         d_c2 = torch.frombuffer(bytearray(cm2), dtype=torch.uint8).to(dev)
         d_v4 = torch.full((P_side,), 77, dtype=torch.uint8, device=dev)
+        d_v5 = torch.full((P_side,), 77, dtype=torch.uint8, device=dev)
         fn = ctx.wip_rangeproof_verify_batch_device if kind else ctx.rangeproof_verify_batch_device
+        calls2 = [0]
 
         def step2():
-            fn(gens2, 64, m, d_p2.data_ptr(), plen2, d_c2.data_ptr(), P_side, d_v4.data_ptr())
+            dv = (d_v4, d_v5)[calls2[0] & 1]  # one verdict buffer per call in flight
+            calls2[0] += 1
+            fn(gens2, 64, m, d_p2.data_ptr(), plen2, d_c2.data_ptr(), P_side, dv.data_ptr())
 
-        for _ in range(max(1, args.warmup)):
+        for _ in range(2 * max(1, args.warmup)):
             step2()
         ctx.sync()
-        if bytes(d_v4.cpu().numpy().tobytes()) != bytes(want2) and not args.skip_check:
-            raise SystemExit("side measurement: verdict mismatch (%s)" % what)
+        for dv in (d_v4, d_v5):
+            if bytes(dv.cpu().numpy().tobytes()) != bytes(want2) and not args.skip_check:
+                raise SystemExit("side measurement: verdict mismatch (%s)" % what)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -847,7 +870,9 @@ def main():
             "dtype": "u32 (256-bit modular integer arithmetic, 9x29-bit limbs on v_mad_u64_u32)",
             "data": "synthetic: %d distinct GPU-made proofs per GPU (SHAKE-256 secrets / blindings / tapes), 1/16 tampered, verdicts checked" % P,
             "config": {"workload": "batch aggregated_verify of %d distinct independent n=64 m=1 Bulletproofs range proofs per GPU per step "
-                                   "(BASELINE.json configs[2]), proofs sharded, no collective" % P,
+                                   "(BASELINE.json configs[2]), proofs sharded, no collective; the K steps are K asynchronous calls, of "
+                                   "which the library keeps %d in flight per GPU (bp_verify_set_overlap)" % (P, 1 if args.no_overlap else 2),
+                       "calls_in_flight": 1 if args.no_overlap else 2,
                        "proofs_per_gpu": P, "msm_terms_per_proof": 147, "table_bytes": gens.table_bytes,
                        "verifier_terms_per_s": value * 147, "batch_generation_s": t_gen},
             "kernel_ms": kms,

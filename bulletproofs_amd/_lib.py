@@ -41,6 +41,7 @@ EXPORTED_SYMBOLS = [
     "bp_rangeproof_verify_batch_device_noalloc",
     "bp_noalloc_scratch_bytes",
     "bp_verify_set_lanes",
+    "bp_verify_set_overlap",
     "bp_scalar_mul_batch",
     "bp_fold_bases",
     "bp_fixed_base_mul_batch",
@@ -140,6 +141,8 @@ def lib():
     L.bp_ctx_sync.restype = i32
     L.bp_verify_set_lanes.argtypes = [vp, i32]
     L.bp_verify_set_lanes.restype = None
+    L.bp_verify_set_overlap.argtypes = [vp, i32]
+    L.bp_verify_set_overlap.restype = None
     L.bp_scalar_mul_batch.argtypes = [vp, cp, cp, sz, cp]
     L.bp_scalar_mul_batch.restype = i32
     L.bp_fold_bases.argtypes = [vp, cp, cp, sz, cp, cp, cp]
@@ -284,6 +287,10 @@ class Context:
 
     def set_verify_lanes(self, lanes):
         lib().bp_verify_set_lanes(self._h, lanes)
+
+    def set_verify_overlap(self, on):
+        """Scalar stage of successive device batch verifications on a side stream (default on; bp_verify_set_overlap)."""
+        lib().bp_verify_set_overlap(self._h, 1 if on else 0)
 
     def rangeproof_verify_batch(self, gens, n_bits, m, proofs, coms_xy):
         """`RangeProof::aggregated_verify` for len(proofs)//proof_len proofs -> list of verdict codes."""

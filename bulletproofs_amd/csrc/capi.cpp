@@ -410,6 +410,11 @@ void bp_ctx_destroy(bp_ctx* ctx) {
         delete ss;
         ctx->srt_streams = nullptr;
     }
+    if (ctx->vside) {
+        (void)hipStreamSynchronize(ctx->vside);
+        (void)hipStreamDestroy(ctx->vside);
+    }
+    if (ctx->v_ev_side) (void)hipEventDestroy(ctx->v_ev_side);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -429,7 +434,7 @@ void bp_proto_set_path(bp_ctx* ctx, int path) {
 
 int bp_msm_device(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be, size_t n, const uint8_t* init_xy, uint8_t out_xy[64]) {
     if (!ctx || !out_xy || (n && (!d_points_xy || !d_scalars_be))) return BP_EINVAL;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream), "memset err");
     int rc;
@@ -447,7 +452,7 @@ size_t bp_msm_partial_bytes(int c) { return (c >= 2 && c <= 15) ? (size_t)glv_wi
 
 int bp_msm_partial_device(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be, size_t n, int c, uint8_t* partial_out) {
     if (!ctx || !partial_out || c < 2 || c > 15 || (n && (!d_points_xy || !d_scalars_be))) return BP_EINVAL;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     const size_t bytes = bp_msm_partial_bytes(c);
     if (n == 0) {  // empty shard: every window sum is the identity (ZZ = 0)
@@ -476,7 +481,7 @@ int bp_msm_partial(bp_ctx* ctx, const uint8_t* points_xy, const uint8_t* scalars
     if (!ctx || !partial_out || (n && (!points_xy || !scalars_be))) return BP_EINVAL;
     void *d_pts = nullptr, *d_sc = nullptr;
     if (n) {
-        std::lock_guard<std::mutex> lk(ctx->mu);
+        CtxLock lk(ctx);
         HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
         int rc;
         if ((rc = ctx->in_points_be.reserve(n * 64)) != BP_OK) return rc;
@@ -491,7 +496,7 @@ int bp_msm_partial(bp_ctx* ctx, const uint8_t* points_xy, const uint8_t* scalars
 
 int bp_msm_combine(bp_ctx* ctx, const uint8_t* partials, size_t nparts, int c, const uint8_t* init_xy, uint8_t out_xy[64]) {
     if (!ctx || !out_xy || c < 2 || c > 15 || (nparts && !partials) || nparts > 4096) return BP_EINVAL;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     const int W = glv_windows(c);
     int rc;
@@ -515,7 +520,7 @@ int bp_msm(bp_ctx* ctx, const uint8_t* points_xy, const uint8_t* scalars_be, siz
     if (!ctx || !out_xy || (n && (!points_xy || !scalars_be))) return BP_EINVAL;
     void *d_pts = nullptr, *d_sc = nullptr;
     {
-        std::lock_guard<std::mutex> lk(ctx->mu);
+        CtxLock lk(ctx);
         HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
         int rc;
         if ((rc = ctx->in_points_be.reserve((n ? n : 1) * 64)) != BP_OK) return rc;

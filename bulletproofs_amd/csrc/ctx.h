@@ -42,6 +42,22 @@ struct bp_ctx {
     int msm_path = 0;  // 0 auto, 1 LDS slice path, 2 sorted path (bp_msm_set_path)
     int msm_pipeline = 0;  // 0 = window groups on side streams (lowest latency of one call), 1 = one group (bp_msm_set_pipeline)
     int verify_lanes = 0;
+    // Batch verifier, asynchronous device entry points (bp_verify_set_overlap, verify_api.cpp): successive calls alternate
+    // between ctx->stream with the context's workspaces and a side lane (own stream, own workspaces `vws`), so that two
+    // batches are in flight and one's latency-bound kernels and kernel tails are filled by the other's work.  Every other
+    // entry point orders ctx->stream after the side lane first (CtxLock below).
+    int verify_overlap = 1;
+    hipStream_t vside = nullptr;
+    hipEvent_t v_ev_side = nullptr;
+    bool v_side_pending = false;
+    unsigned v_calls = 0;
+    bp::DevBuf vws[8];
+    void join_side() {
+        if (v_side_pending) {
+            (void)hipStreamWaitEvent(stream, v_ev_side, 0);
+            v_side_pending = false;
+        }
+    }
     int proto_path = 0;  // protocol layer: 0 = every generator MSM from the fixed-base table, 1 = reference-structured (bp_proto_set_path)
     // optional per-kernel timing (bp_profile_*): HIP events on this context's stream
     bool profiling = false;
@@ -74,6 +90,7 @@ struct bp_ctx {
         lam.release();
         for (auto& s : srt) s.release();
         for (auto& s : scratch) s.release();
+        for (auto& s : vws) s.release();
         vartab.release();
         fixres.release();
         fixpart.release();
@@ -84,6 +101,13 @@ struct bp_ctx {
         h_pin = nullptr;
         h_pin_cap = 0;
     }
+};
+
+// Lock of an entry point: the context's mutex, then ctx->stream ordered after the batch verifier's side lane (a no-op unless
+// an overlapped verification is pending there).
+struct CtxLock {
+    std::unique_lock<std::mutex> lk;
+    explicit CtxLock(bp_ctx* ctx) : lk(ctx->mu) { ctx->join_side(); }
 };
 
 // Opaque `bp_gens` of include/bpmsm.h: generators in limb form + fixed-base window table in HBM.

@@ -671,7 +671,7 @@ int bp_generate_bases_device(bp_ctx* ctx, int kind, uint64_t seed, size_t n_bits
     if (kind == 1 && seed == 0) return BP_EINVAL;
     if (n_bits > ((size_t)1 << 20) || m > ((size_t)1 << 20) || n_bits * m > ((size_t)1 << 24)) return BP_EINVAL;
     const size_t nm = n_bits * m, np = 2 * nm + 2;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     RC(ctx->proto[4].reserve(np * sizeof(affine_mem)));
     RC(ctx->proto[5].reserve(np * 64));
@@ -690,7 +690,7 @@ int bp_generate_bases_device(bp_ctx* ctx, int kind, uint64_t seed, size_t n_bits
 int bp_scalar_mul_batch(bp_ctx* ctx, const uint8_t* points_xy, const uint8_t* scalars_be, size_t n, uint8_t* out_xy) {
     if (!ctx || (n && (!points_xy || !scalars_be || !out_xy))) return BP_EINVAL;
     if (!n) return BP_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     RC(ctx->proto[4].reserve(n * sizeof(affine_mem)));
     RC(ctx->proto[5].reserve(n * sizeof(affine_mem)));
@@ -705,7 +705,7 @@ int bp_fold_bases(bp_ctx* ctx, const uint8_t* lo_xy, const uint8_t* hi_xy, size_
                   uint8_t* out_xy) {
     if (!ctx || !s_lo || !s_hi || (n_half && (!lo_xy || !hi_xy || !out_xy))) return BP_EINVAL;
     if (!n_half) return BP_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     RC(ctx->proto[4].reserve(2 * n_half * sizeof(affine_mem)));
     RC(ctx->proto[5].reserve(n_half * sizeof(affine_mem)));
@@ -740,8 +740,12 @@ int bp_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint
     const size_t plen = 292 + 66 * (size_t)k;
     if (proof_cap < plen || tape_len < 32 * (2 * nm + 4)) return BP_EINVAL;
     std::unique_lock<std::mutex> lk(ctx->mu, std::defer_lock);
-    if (!tl_batcher) lk.lock();  // inside a batch the batch call holds ctx->mu and only the batcher touches the context
-    else if (ctx->proto_path != 0) return BP_EINVAL;
+    if (!tl_batcher) {  // inside a batch the batch call holds ctx->mu and only the batcher touches the context
+        lk.lock();
+        ctx->join_side();
+    } else if (ctx->proto_path != 0) {
+        return BP_EINVAL;
+    }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     Gens gn(gens);
     Tape tp{tape, tape_len};
@@ -867,7 +871,7 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
         set_error_msg("sizes: nm must be a power of two equal to the generators' nm; proof_len = 292 + 66 log2(nm)");
         return BP_EINVAL;
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     Gens gn(gens);
     BpProof pf;
@@ -1237,8 +1241,12 @@ int bp_wip_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const 
     const size_t plen = 195 + 66 * (size_t)k;
     if (proof_cap < plen || tape_len < 32 * (size_t)(1 + 2 * k + 4)) return BP_EINVAL;
     std::unique_lock<std::mutex> lk(ctx->mu, std::defer_lock);
-    if (!tl_batcher) lk.lock();
-    else if (ctx->proto_path != 0) return BP_EINVAL;
+    if (!tl_batcher) {
+        lk.lock();
+        ctx->join_side();
+    } else if (ctx->proto_path != 0) {
+        return BP_EINVAL;
+    }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     Gens gn(gens);
     Tape tp{tape, tape_len};
@@ -1306,7 +1314,7 @@ int bp_wip_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
         set_error_msg("sizes: nm must be a power of two equal to the generators' nm; proof_len = 195 + 66 log2(nm)");
         return BP_EINVAL;
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     Gens gn(gens);
     BpPlusProof pf;
@@ -1472,7 +1480,7 @@ int bp_ipa_prove(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t n
     const size_t len = 66 * (size_t)k + 64;
     if (arg_cap < len) return BP_EINVAL;
     if (!pt_valid(ux_xy)) return BP_EPOINT;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     affine_mem* d;
     RC(upload_arg_bases(ctx, g_xy, h_xy, n, ux_xy, nullptr, &d));
@@ -1512,7 +1520,7 @@ int bp_ipa_verify(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* hi_tag_xy, si
     }
     p.a = Fq::from_be(q);
     p.b = Fq::from_be(q + 32);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     affine_mem* d;
     RC(upload_arg_bases(ctx, g_xy, hi_tag_xy, n, ux_xy, nullptr, &d));
@@ -1567,7 +1575,7 @@ int bp_wipa_prove(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t 
     const size_t len = 66 * (size_t)k + 162;
     if (arg_cap < len || tape_len < 32 * (size_t)(2 * k + 4)) return BP_EINVAL;
     if (!pt_valid(g_pt) || !pt_valid(h_pt)) return BP_EPOINT;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     affine_mem* d;
     RC(upload_arg_bases(ctx, g_xy, h_xy, n, g_pt, h_pt, &d));
@@ -1619,7 +1627,7 @@ int bp_wipa_verify(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* hi_tag_xy, s
     w.r_prime = Fq::from_be(q);
     w.s_prime = Fq::from_be(q + 32);
     w.delta_prime = Fq::from_be(q + 64);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     affine_mem* d;
     RC(upload_arg_bases(ctx, g_xy, hi_tag_xy, n, g_pt, h_pt, &d));
@@ -1679,7 +1687,7 @@ static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
         set_error_msg("prove_batch: n_bits*m must be a power of two equal to the generators' nm; proof_len = 292 (195 for BP+) + 66 log2(nm)");
         return BP_EINVAL;
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     if (ctx->proto_path != 0) {
         set_error_msg("prove_batch needs the fixed-base table path (bp_proto_set_path(ctx, 0))");
         return BP_EINVAL;

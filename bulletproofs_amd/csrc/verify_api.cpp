@@ -55,7 +55,7 @@ int bp_gens_create(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h_xy, size_t
                    int window_bits, bp_gens** out) {
     if (!ctx || !out || !g_xy || !h_xy || !G_xy || !H_xy || nm == 0 || nm > (1u << 20)) return BP_EINVAL;
     *out = nullptr;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     const int np = (int)(2 * nm + 2) + (memcmp(G_xy, kSecpGenerator, 64) != 0 ? 1 : 0);  // table rows (see bp_gens::ibase)
     int c = window_bits ? window_bits : pick_table_window(np);
@@ -164,6 +164,11 @@ size_t bp_gens_table_bytes(const bp_gens* g) { return g ? g->table_bytes : 0; }
 void bp_verify_set_lanes(bp_ctx* ctx, int lanes) {
     if (ctx) ctx->verify_lanes = lanes;
 }
+void bp_verify_set_overlap(bp_ctx* ctx, int on) {
+    if (!ctx) return;
+    CtxLock lk(ctx);
+    ctx->verify_overlap = on != 0;
+}
 
 // fold the event pairs of the pending call into the accumulators (stream must be idle)
 static void prof_collect(bp_ctx* ctx) {
@@ -182,8 +187,10 @@ static void prof_mark(bp_ctx* ctx, int slot) {
 
 int bp_ctx_sync(bp_ctx* ctx) {
     if (!ctx) return BP_EINVAL;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    if (ctx->vside) HIPCHK(hipStreamSynchronize(ctx->vside), "sync");
+    ctx->v_side_pending = false;
     HIPCHK(hipStreamSynchronize(ctx->stream), "sync");
     if (ctx->profiling) prof_collect(ctx);
     return BP_OK;
@@ -191,7 +198,7 @@ int bp_ctx_sync(bp_ctx* ctx) {
 
 void bp_profile_enable(bp_ctx* ctx, int on) {
     if (!ctx) return;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     (void)hipSetDevice(ctx->device);
     if (on && !ctx->prof_ev[0]) {
         for (int i = 0; i <= bp_ctx::kMaxProf; i++) (void)hipEventCreate(&ctx->prof_ev[i]);
@@ -201,7 +208,7 @@ void bp_profile_enable(bp_ctx* ctx, int on) {
 }
 void bp_profile_reset(bp_ctx* ctx) {
     if (!ctx) return;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     for (int i = 0; i < bp_ctx::kMaxProf; i++) {
         ctx->prof_ms[i] = 0;
         ctx->prof_calls[i] = 0;
@@ -210,7 +217,7 @@ void bp_profile_reset(bp_ctx* ctx) {
 }
 int bp_profile_get(bp_ctx* ctx, int kernel_id, double* total_ms, long* launches) {
     if (!ctx || kernel_id < 0 || kernel_id >= bp_ctx::kMaxProf) return BP_EINVAL;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     if (total_ms) *total_ms = ctx->prof_ms[kernel_id];
     if (launches) *launches = ctx->prof_calls[kernel_id];
     return BP_OK;
@@ -296,44 +303,72 @@ static VerifySizes verify_ws_sizes(const bp_ctx* ctx, const bp_gens* gens, int n
 }
 
 static int verify_batch_launch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, const void* d_proofs, size_t proof_len,
-                               const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip, const VerifyWs& ws, int tp);
+                               const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip, const VerifyWs& ws, int tp, hipStream_t st);
 static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, const void* d_proofs, size_t proof_len,
-                                      const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip = 0);
+                                      const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip = 0, bool overlap = false);
 
 int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
                                       const void* d_coms_xy, size_t nproofs, void* d_verdicts) {
     int k = 0;
     int rc = check_batch_args(ctx, gens, n_bits, m, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, &k);
     if (rc != BP_OK || nproofs == 0) return rc;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    return verify_batch_device_nolock(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts);
+    std::lock_guard<std::mutex> lk(ctx->mu);  // no CtxLock: this call may run beside the side lane's
+    return verify_batch_device_nolock(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, 0, true);
+}
+
+// the side lane's stream and event, created at first use
+static int verify_overlap_init(bp_ctx* ctx) {
+    if (ctx->vside) return BP_OK;
+    HIPCHK(hipStreamCreateWithFlags(&ctx->vside, hipStreamNonBlocking), "hipStreamCreate");
+    HIPCHK(hipEventCreateWithFlags(&ctx->v_ev_side, hipEventDisableTiming), "hipEventCreate");
+    return BP_OK;
 }
 
 // wip = 1: Bulletproofs+ (RangeProofWIP::aggregated_verify, range_proof_wip.rs:388-609): own decompression order and
 // scalar pipeline, the same MSM kernel (its variable terms and comparand follow the point order, verify_kernels.hip)
+// overlap = true (the asynchronous device entry points only): every second call goes to the side lane - ctx->vside and the
+// workspaces ctx->vws, which nothing else uses - and runs beside the call before and after it on ctx->stream.  Measured on
+// 65 536 n=64 m=1 proofs per call: 16.1 -> 14.7 ms per call (the scalar kernels are latency-bound at one wave per SIMD, the
+// table kernel leaves a quarter of its workgroups to a second, thin round, the ladder kernel waits on its window tables:
+// another batch's waves take those slots).  Not while per-stage timing is on (stages of two calls would interleave), not
+// for callers whose inputs are written on ctx->stream (the side lane does not wait for that stream).
 static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, const void* d_proofs, size_t proof_len,
-                                      const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip) {
+                                      const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip, bool overlap) {
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     const VerifySizes z = verify_ws_sizes(ctx, gens, n_bits, m, k, nproofs, wip);
     int rc;
-    DevBuf &b_pts = ctx->scratch[0], &b_bad = ctx->scratch[1], &b_dig = ctx->scratch[2], &b_var = ctx->scratch[3], &b_s = ctx->scratch[4];
+    bool side = false;
+    if (overlap && ctx->verify_overlap && !ctx->profiling) {
+        if ((rc = verify_overlap_init(ctx)) != BP_OK) return rc;
+        side = (ctx->v_calls++ & 1u) != 0;
+    } else {
+        ctx->join_side();  // a serial call after overlapped ones (overlap switched off, per-stage timing switched on)
+    }
+    DevBuf* w = side ? ctx->vws : nullptr;
+    DevBuf &b_pts = w ? w[0] : ctx->scratch[0], &b_bad = w ? w[1] : ctx->scratch[1], &b_dig = w ? w[2] : ctx->scratch[2],
+           &b_var = w ? w[3] : ctx->scratch[3], &b_s = w ? w[4] : ctx->scratch[4], &b_fixres = w ? w[5] : ctx->fixres,
+           &b_vartab = w ? w[6] : ctx->vartab, &b_fixpart = w ? w[7] : ctx->fixpart;
     if ((rc = b_pts.reserve(z.pts)) != BP_OK) return rc;
     if ((rc = b_bad.reserve(z.bad)) != BP_OK) return rc;
     if ((rc = b_dig.reserve(z.dig)) != BP_OK) return rc;
     if ((rc = b_var.reserve(z.var)) != BP_OK) return rc;
     if ((rc = b_s.reserve(z.chal)) != BP_OK) return rc;
-    if ((rc = ctx->fixres.reserve(z.fixres)) != BP_OK) return rc;
-    if ((rc = ctx->vartab.reserve(z.vartab)) != BP_OK) return rc;
-    if ((rc = ctx->fixpart.reserve(z.fixpart)) != BP_OK) return rc;
-    VerifyWs ws{(affine_mem*)b_pts.p, (int*)b_bad.p, (tdig_t*)b_dig.p, (fq*)b_var.p, (fq*)b_s.p, (xyzz*)ctx->fixres.p, (xyzz*)ctx->vartab.p,
-                (xyzz*)ctx->fixpart.p};
-    return verify_batch_launch(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, wip, ws, z.tp);
+    if ((rc = b_fixres.reserve(z.fixres)) != BP_OK) return rc;
+    if ((rc = b_vartab.reserve(z.vartab)) != BP_OK) return rc;
+    if ((rc = b_fixpart.reserve(z.fixpart)) != BP_OK) return rc;
+    VerifyWs ws{(affine_mem*)b_pts.p, (int*)b_bad.p, (tdig_t*)b_dig.p, (fq*)b_var.p, (fq*)b_s.p, (xyzz*)b_fixres.p, (xyzz*)b_vartab.p,
+                (xyzz*)b_fixpart.p};
+    rc = verify_batch_launch(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, wip, ws, z.tp, side ? ctx->vside : ctx->stream);
+    if (side) {
+        HIPCHK(hipEventRecord(ctx->v_ev_side, ctx->vside), "record event");
+        ctx->v_side_pending = true;
+    }
+    return rc;
 }
 
-// the kernels of one batch verification on the context's stream; allocates nothing
+// the kernels of one batch verification on stream st (the context's, or the side lane's); allocates nothing
 static int verify_batch_launch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, const void* d_proofs, size_t proof_len,
-                               const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip, const VerifyWs& ws, int tp) {
-    hipStream_t st = ctx->stream;
+                               const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip, const VerifyWs& ws, int tp, hipStream_t st) {
     fq* d_chal = ws.chal;
     fq* d_cst = d_chal + nproofs * bpv_chal_count(k);
     xyzz* d_fixres = ws.fixres;
@@ -409,7 +444,7 @@ int bp_rangeproof_verify_batch_device_noalloc(bp_ctx* ctx, const bp_gens* gens, 
     int k = 0;
     int rc = check_batch_args(ctx, gens, n_bits, m, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, &k);
     if (rc != BP_OK || nproofs == 0) return rc;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     unsigned char* base = ctx->device < kMaxDevices ? g_scratch_ptr[ctx->device] : nullptr;
     if (!base) {
@@ -443,7 +478,7 @@ int bp_rangeproof_verify_batch_device_noalloc(bp_ctx* ctx, const bp_gens* gens, 
     ws.fixpart = (xyzz*)carve(z.fixpart);
     // The array keeps the previous call's contents.  Only `bad` must start at zero (verify_batch_launch clears it on the
     // stream); every other slice is written by the kernels of this call before it is read.
-    return verify_batch_launch(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, 0, ws, z.tp);
+    return verify_batch_launch(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, 0, ws, z.tp, ctx->stream);
 }
 
 int bp_wip_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
@@ -451,8 +486,8 @@ int bp_wip_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int 
     int k = 0;
     int rc = check_batch_args(ctx, gens, n_bits, m, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, &k, 1);
     if (rc != BP_OK || nproofs == 0) return rc;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    return verify_batch_device_nolock(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, 1);
+    std::lock_guard<std::mutex> lk(ctx->mu);  // no CtxLock: this call may run beside the side lane's
+    return verify_batch_device_nolock(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, 1, true);
 }
 
 // Random-linear-combination batch verification (rlc_kernels.hip).  Synchronous: returns with the verdicts
@@ -466,7 +501,7 @@ static int verify_batch_rlc_device_impl(bp_ctx* ctx, const bp_gens* gens, int n_
     if (!seed) return BP_EINVAL;
     if (used_fallback) *used_fallback = 0;
     if (nproofs == 0) return BP_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = ctx->stream;
     const int NPT = (wip ? 3 : 4) + 2 * k + m, NV = (wip ? 2 : 3) + 2 * k + m, np = gens->np, W = gens->W;
@@ -589,7 +624,7 @@ int bp_msm_batch(bp_ctx* ctx, const bp_gens* gens, const bp_msm_job* jobs, size_
         memcpy(&xp[(size_t)xoff[j] * 64], jobs[j].extra_points_xy, jobs[j].n_extra * 64);
         memcpy(&xs[(size_t)xoff[j] * 32], jobs[j].extra_scalars_be, jobs[j].n_extra * 32);
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t st = ctx->stream;
     int rc;
@@ -635,10 +670,21 @@ int bp_msm_batch(bp_ctx* ctx, const bp_gens* gens, const bp_msm_job* jobs, size_
     return BP_OK;
 }
 
+// The batch verifier entirely on ctx->stream, for callers whose inputs are produced on that stream (the host-pointer entry
+// points stage them with hipMemcpyAsync): the overlapped form's side stream would not wait for them.
+static int verify_batch_device_serial(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
+                                      const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip) {
+    int k = 0;
+    int rc = check_batch_args(ctx, gens, n_bits, m, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, &k, wip);
+    if (rc != BP_OK || nproofs == 0) return rc;
+    CtxLock lk(ctx);
+    return verify_batch_device_nolock(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, wip, false);
+}
+
 // host buffers -> device staging (scratch[5..7]); shared by the two host-pointer batch verifiers
 static int stage_batch(bp_ctx* ctx, const uint8_t* proofs, size_t proof_len, const uint8_t* coms_xy, int m, size_t nproofs, void** d_p, void** d_c,
                        void** d_v) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     int rc;
     if ((rc = ctx->scratch[5].reserve(nproofs * proof_len)) != BP_OK) return rc;
@@ -691,7 +737,7 @@ int bp_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int
     if (!proofs || !coms_xy || !verdicts) return BP_EINVAL;
     void *d_p, *d_c, *d_v;
     if (int rcs = stage_batch(ctx, proofs, proof_len, coms_xy, m, nproofs, &d_p, &d_c, &d_v)) return rcs;
-    int rc = bp_rangeproof_verify_batch_device(ctx, gens, n_bits, m, d_p, proof_len, d_c, nproofs, d_v);
+    int rc = verify_batch_device_serial(ctx, gens, n_bits, m, d_p, proof_len, d_c, nproofs, d_v, 0);  // staged on ctx->stream: no overlap
     if (rc != BP_OK) return rc;
     std::vector<uint8_t> tmp(nproofs);
     HIPCHK(hipMemcpyAsync(tmp.data(), d_v, nproofs, hipMemcpyDeviceToHost, ctx->stream), "memcpy verdicts");
@@ -708,7 +754,7 @@ int bp_wip_rangeproof_verify_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits,
     if (!proofs || !coms_xy || !verdicts) return BP_EINVAL;
     void *d_p, *d_c, *d_v;
     if (int rcs = stage_batch(ctx, proofs, proof_len, coms_xy, m, nproofs, &d_p, &d_c, &d_v)) return rcs;
-    int rc = bp_wip_rangeproof_verify_batch_device(ctx, gens, n_bits, m, d_p, proof_len, d_c, nproofs, d_v);
+    int rc = verify_batch_device_serial(ctx, gens, n_bits, m, d_p, proof_len, d_c, nproofs, d_v, 1);
     if (rc != BP_OK) return rc;
     std::vector<uint8_t> tmp(nproofs);
     HIPCHK(hipMemcpyAsync(tmp.data(), d_v, nproofs, hipMemcpyDeviceToHost, ctx->stream), "memcpy verdicts");
@@ -765,7 +811,7 @@ static int verify_batch_mixed(bp_ctx* ctx, const bp_gens* gens, int n_bits, cons
         int rc = stage_batch(ctx, pb.data(), plen, cb.data(), g.m, cnt, &d_p, &d_c, &d_v);
         if (rc != BP_OK) return rc;
         {
-            std::lock_guard<std::mutex> lk(ctx->mu);
+            CtxLock lk(ctx);
             rc = verify_batch_device_nolock(ctx, gens, n_bits, g.m, g.k, d_p, plen, d_c, cnt, d_v, wip);
             if (rc != BP_OK) return rc;
             HIPCHK(hipMemcpyAsync(vb.data(), d_v, cnt, hipMemcpyDeviceToHost, ctx->stream), "memcpy verdicts");

@@ -187,6 +187,15 @@ int bp_rangeproof_verify_batch_rlc_device(bp_ctx* ctx, const bp_gens* gens, int 
 /* Tuning knob: lanes per proof in the verifier's MSM kernel (2, 4, 8, 16, 32 or 64; 0 = chosen by batch size; -4 = the
  * small-batch kernel with four lanes per proof-specific point, which 0 picks by itself when the batch is latency-bound). */
 void bp_verify_set_lanes(bp_ctx* ctx, int lanes);
+/* Overlap of successive bp_rangeproof_verify_batch_device / bp_wip_rangeproof_verify_batch_device calls (default on):
+ * the scalar stage of a call (point decompression, Fiat-Shamir challenges, the 2nm+2 generator scalars; short,
+ * latency-bound kernels) runs on a side stream into one of two workspace sets, beside the previous call's table and
+ * ladder kernels, which fill the GPU on the context's stream; verdicts are still written in call order on the
+ * context's stream.  The side stream does not wait for earlier work of the context: the proofs and commitments must be
+ * complete in device memory when the call is made (they are for any caller that filled them on its own streams and
+ * synchronised; the host-pointer entry points, which stage their inputs on the context's stream, never overlap).
+ * on = 0: every kernel on the context's stream. */
+void bp_verify_set_overlap(bp_ctx* ctx, int on);
 
 /* bp_scalar_mul_batch — n independent out[i] = scalars[i] * points[i].
  * Replaces `hi_tag[i] = &h_vec[i] * &yi_inv[i]` (range_proof.rs:231-233, 327-329, 462-464). */

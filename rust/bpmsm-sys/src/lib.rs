@@ -63,6 +63,7 @@ extern "C" {
     pub fn bp_msm_set_pipeline(ctx: *mut bp_ctx, mode: c_int);
     pub fn bp_proto_set_path(ctx: *mut bp_ctx, path: c_int);
     pub fn bp_verify_set_lanes(ctx: *mut bp_ctx, lanes: c_int);
+    pub fn bp_verify_set_overlap(ctx: *mut bp_ctx, on: c_int);
 
     // g_vec / h_vec / G / H, uploaded once and expanded into the fixed-base window table
     pub fn bp_gens_create(ctx: *mut bp_ctx, g_xy: *const u8, h_xy: *const u8, nm: usize, G_xy: *const u8, H_xy: *const u8,

@@ -432,3 +432,52 @@ def test_serde_wire_format_feeds_the_verifier(ctx, fmt):
         assert want[0] == 0 and any(v != 0 for v in want)
     finally:
         gens.close()
+
+
+def test_overlapped_device_calls_match_the_serial_form(ctx):
+    """Successive asynchronous device calls alternate between the context's stream and a side lane with its own workspaces
+    (bp_verify_set_overlap, default on), so two batches are in flight.  Seven calls of different sizes and tamper patterns
+    with no sync in between - sizes going up and down so that both lanes' workspaces are re-allocated while the other lane
+    is busy, and a host-pointer call (which must first order the context's stream after the side lane) in the middle - must
+    give the verdict bytes of the same calls with the overlap off."""
+    import torch
+    dev = torch.device("cuda", 0)
+    b, gens, proofs, coms, plen = _c3(ctx, 10)
+    try:
+        def batch(count, tamper_every, mal_at):
+            pb, cb = bytearray(), bytearray()
+            for j in range(count):
+                i = (j * 11 + tamper_every) % b["count"]
+                p = bytearray(proofs[i * plen:(i + 1) * plen])
+                if j % tamper_every == 2:
+                    p[4 * 33 + 64 + 31] ^= 1   # tx
+                if j == mal_at:
+                    p[33] = 7                  # S: not a SEC1 prefix
+                pb += p
+                cb += coms[i * 64:(i + 1) * 64]
+            return pb, cb
+        shapes = [(300, 3, 5), (40, 4, 0), (1500, 5, 1499), (7, 6, 3), (1500, 7, 2), (256, 3, 100), (900, 4, 899)]
+        inputs = []
+        for count, te, mal in shapes:
+            pb, cb = batch(count, te, mal)
+            inputs.append((count, torch.frombuffer(pb, dtype=torch.uint8).to(dev), torch.frombuffer(cb, dtype=torch.uint8).to(dev), bytes(pb), bytes(cb)))
+        torch.cuda.synchronize()
+        results = {}
+        for overlap in (0, 1):
+            ctx.set_verify_overlap(overlap)
+            outs = [torch.full((c,), 77, dtype=torch.uint8, device=dev) for c, *_ in inputs]
+            torch.cuda.synchronize()
+            host = None
+            for r, (count, d_p, d_c, pb, cb) in enumerate(inputs):
+                ctx.rangeproof_verify_batch_device(gens, 64, 1, d_p.data_ptr(), plen, d_c.data_ptr(), count, outs[r].data_ptr())
+                if r == 3:
+                    host = ctx.rangeproof_verify_batch(gens, 64, 1, inputs[1][3], inputs[1][4])
+            ctx.sync()
+            results[overlap] = [o.cpu().tolist() for o in outs] + [host]
+        assert results[1] == results[0]
+        for (count, te, mal), got in zip(shapes, results[1]):
+            assert got == [255 if j == mal else (3 if j % te == 2 else 0) for j in range(count)]
+        assert results[1][-1] == results[1][1]
+    finally:
+        ctx.set_verify_overlap(1)
+        gens.close()
