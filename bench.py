@@ -906,6 +906,14 @@ def main():
                         "verifier does not execute, so it is not a bound for this kernel",
                 "proofs_per_launch": P,
                 "avg_launch_ms": msm_ms,
+                "avg_launch_ms_what": "k_bpv_fix + k_bpv_msm of one call with the GPU to themselves (HIP events on the library's stream, calls "
+                                      "one at a time: per-stage timing switches the overlap of successive calls off); agrees with "
+                                      "profiles/r02_bench_kernel_stats_serial.csv (rocprofv3 of bench.py --no-overlap).  In the timed region two "
+                                      "calls are in flight and each kernel's wall time stretches while it shares the GPU "
+                                      "(profiles/r02_bench_kernel_stats.csv), so the rate of the whole pipelined step is given beside it",
+                "frac_whole_step": (EXEC_MAD32_PER_PROOF_MSM if counted else MAD32_PER_PROOF_MSM) * value / world / PEAK_MAD32_PER_S,
+                "frac_whole_step_what": "the same MADs per proof (MSM pair only) x proofs/s per GPU / peak: the whole step, decompression and "
+                                        "scalar kernels included, as the timed region runs it",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

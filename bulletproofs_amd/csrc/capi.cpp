@@ -245,7 +245,7 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
             SortedStreams* ss = new SortedStreams();
             memset(ss, 0, sizeof(*ss));
             ctx->srt_streams = ss;
-            HIPCHK(hipStreamCreateWithFlags(&ss->st2, hipStreamNonBlocking), "hipStreamCreate");
+            HIPCHK(ctx->side_stream(&ss->st2), "hipStreamCreate");  // the context's side stream (ctx.h)
             HIPCHK(hipStreamCreateWithFlags(&ss->st3, hipStreamNonBlocking), "hipStreamCreate");
             ss->st4 = ss->st2;  // a stream of its own shared st3's hardware queue (4 per process) and serialised the two
             for (int g = 0; g < SortedStreams::kMaxGroups; g++) {
@@ -394,10 +394,8 @@ void bp_ctx_destroy(bp_ctx* ctx) {
     for (int i = 0; i <= bp_ctx::kMaxProf; i++)
         if (ctx->prof_ev[i]) (void)hipEventDestroy(ctx->prof_ev[i]);
     if (SortedStreams* ss = ctx->srt_streams) {
-        if (ss->st2) (void)hipStreamSynchronize(ss->st2);
         if (ss->st3) (void)hipStreamSynchronize(ss->st3);
-        if (ss->st2) (void)hipStreamDestroy(ss->st2);
-        if (ss->st3) (void)hipStreamDestroy(ss->st3);
+        if (ss->st3) (void)hipStreamDestroy(ss->st3);  // (st2 is the context's side stream, destroyed below)
         for (int g = 0; g < SortedStreams::kMaxGroups; g++) {
             if (ss->ev_acc[g]) (void)hipEventDestroy(ss->ev_acc[g]);
             if (ss->ev_red[g]) (void)hipEventDestroy(ss->ev_red[g]);

@@ -47,7 +47,18 @@ struct bp_ctx {
     // batches are in flight and one's latency-bound kernels and kernel tails are filled by the other's work.  Every other
     // entry point orders ctx->stream after the side lane first (CtxLock below).
     int verify_overlap = 1;
+    // ONE side stream per context, shared by the verifier's side lane and the sorted MSM's sort / Horner stream (st2): a process
+    // has four hardware queues, and a fifth stream lands on an occupied queue and serialises with it (measured: the 2^20-point
+    // MSM 2.3 -> 3.0 ms with a separate verifier stream created first).  Work of the two users never depends on each other.
     hipStream_t vside = nullptr;
+    hipError_t side_stream(hipStream_t* out) {
+        if (!vside) {
+            hipError_t e = hipStreamCreateWithFlags(&vside, hipStreamNonBlocking);
+            if (e != hipSuccess) return e;
+        }
+        *out = vside;
+        return hipSuccess;
+    }
     hipEvent_t v_ev_side = nullptr;
     bool v_side_pending = false;
     unsigned v_calls = 0;

@@ -318,8 +318,9 @@ int bp_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bi
 
 // the side lane's stream and event, created at first use
 static int verify_overlap_init(bp_ctx* ctx) {
-    if (ctx->vside) return BP_OK;
-    HIPCHK(hipStreamCreateWithFlags(&ctx->vside, hipStreamNonBlocking), "hipStreamCreate");
+    if (ctx->v_ev_side) return BP_OK;
+    hipStream_t s;
+    HIPCHK(ctx->side_stream(&s), "hipStreamCreate");
     HIPCHK(hipEventCreateWithFlags(&ctx->v_ev_side, hipEventDisableTiming), "hipEventCreate");
     return BP_OK;
 }

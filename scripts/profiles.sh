@@ -5,6 +5,8 @@ O=gpurun_out/prof; rm -rf $O; mkdir -p $O
 set -e
 timeout -k 10 300 python3 bench.py > $O/bench.json 2> $O/bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt.err
+# the same with successive calls one after the other: per-kernel durations with the GPU to themselves (roofline.avg_launch_ms)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt_serial -o kt -- python3 bench.py --no-cpu-baseline --no-overlap --no-rlc --no-bpplus --no-c2 --no-msm --no-tiled > $O/bench_serial_under_rocprof.json 2> $O/kt_serial.err
 timeout -s KILL 200 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $O/pmc_rd -o pmc -- python3 bench.py --no-cpu-baseline --no-rlc --no-bpplus --no-c2 --steps 3 --warmup 1 > $O/pmc_rd.json 2> $O/pmc_rd.err
 timeout -s KILL 200 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d $O/pmc_wr -o pmc -- python3 bench.py --no-cpu-baseline --no-rlc --no-bpplus --no-c2 --steps 3 --warmup 1 > $O/pmc_wr.json 2> $O/pmc_wr.err
 timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE -d $O/pmc_valu -o pmc -- python3 bench.py --no-cpu-baseline --no-rlc --no-bpplus --no-c2 --steps 3 --warmup 1 > $O/pmc_valu.json 2> $O/pmc_valu.err
@@ -17,6 +19,6 @@ timeout -k 10 300 python3 bench.py --workload prove --steps 8 > $O/prove_latency
 timeout -k 10 300 python3 scripts/experiments/bigtable_test.py 4096 12,14,16 > $O/bigtable.txt 2> $O/bigtable.err
 timeout -k 10 120 ./bench_micro/ecops > $O/ecops.jsonl 2> $O/ecops.err
 timeout -k 10 120 ./bench_micro/peak_mad32 > $O/peak_mad32.jsonl 2> $O/peak.err
-for d in kt pmc_rd pmc_wr pmc_valu msm_kt msm_pmc_rd msm_pmc_wr; do f=$(ls $O/$d/*_results.db); m=pmc; case $d in kt|msm_kt) m=stats;; esac; python3 profiles/summarize.py $m $f $O/$d.csv; rm -rf $O/$d; done  # raw rocprof databases stay on the box (gpurun merges back <= 64 MiB)
+for d in kt kt_serial pmc_rd pmc_wr pmc_valu msm_kt msm_pmc_rd msm_pmc_wr; do f=$(ls $O/$d/*_results.db); m=pmc; case $d in kt|kt_serial|msm_kt) m=stats;; esac; python3 profiles/summarize.py $m $f $O/$d.csv; rm -rf $O/$d; done  # raw rocprof databases stay on the box (gpurun merges back <= 64 MiB)
 du -sh $O
 echo PROFILES_OK
