@@ -389,6 +389,7 @@ void bp_ctx_destroy(bp_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->vside) (void)hipStreamSynchronize(ctx->vside);  // the verifier's side lane may still be running
     ctx->release_all();
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     for (int i = 0; i <= bp_ctx::kMaxProf; i++)

@@ -65,6 +65,7 @@ struct bp_ctx {
     bp::DevBuf vws[8];
     void join_side() {
         if (v_side_pending) {
+            (void)hipSetDevice(device);
             (void)hipStreamWaitEvent(stream, v_ev_side, 0);
             v_side_pending = false;
         }
