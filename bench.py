@@ -45,6 +45,7 @@ MAD32_PER_POINT_MSM = 11833.0       # SURVEY.md 8(d), C5 model (2^20 points, c =
 #   k_bpv_msm, n=64 m=1, 20-bit table, 2 lanes per proof: 23 900 fp_mul + 7 223 fp_sqr per proof
 #   whole bp_msm_device pipeline at 2^20 points:           157.0 fp_mul + 39.4 fp_sqr per point
 EXEC_MAD32_PER_PROOF_MSM = 2.907e6
+EXEC_MAD32_PER_PROOF_DECOMPRESS = 0.270e6  # k_bpv_decompress: 211 fp_mul + 3827 fp_sqr per proof (19 square roots), same file
 EXEC_MAD32_PER_POINT_MSM = 18578.0
 # HBM-side traffic of one verification MSM (the launch pair k_bpv_fix + k_bpv_msm) at the default configuration (65536
 # distinct proofs, auto lanes, 20-bit table windows), from the separate --pmc passes in profiles/r02_pmc_read.csv /
@@ -901,7 +902,7 @@ def main():
                 "executed_mad32_per_proof": EXEC_MAD32_PER_PROOF_MSM if counted else None,
                 "model_mad32_per_proof": MAD32_PER_PROOF_MSM,
                 "what": "frac = frac_executed: v_mad_u64_u32 lane-results the kernel executes per proof (counted by the instrumented build, "
-                        "profiles/r02_opcount.json: field multiplications x 91 + squarings x 55) x proofs / launch time / measured peak; "
+                        "profiles/r02_opcount.json: field multiplications x 102 + squarings x 65, the v_mad_u64_u32 of their ISA) x proofs / launch time / measured peak; "
                         "frac_model: SURVEY 8(d)'s Pippenger model (146 points, c=5), which charges doublings and buckets a table-based "
                         "verifier does not execute, so it is not a bound for this kernel",
                 "proofs_per_launch": P,
@@ -911,9 +912,11 @@ def main():
                                       "profiles/r02_bench_kernel_stats_serial.csv (rocprofv3 of bench.py --no-overlap).  In the timed region two "
                                       "calls are in flight and each kernel's wall time stretches while it shares the GPU "
                                       "(profiles/r02_bench_kernel_stats.csv), so the rate of the whole pipelined step is given beside it",
-                "frac_whole_step": (EXEC_MAD32_PER_PROOF_MSM if counted else MAD32_PER_PROOF_MSM) * value / world / PEAK_MAD32_PER_S,
-                "frac_whole_step_what": "the same MADs per proof (MSM pair only) x proofs/s per GPU / peak: the whole step, decompression and "
-                                        "scalar kernels included, as the timed region runs it",
+                "frac_whole_step": ((EXEC_MAD32_PER_PROOF_MSM + EXEC_MAD32_PER_PROOF_DECOMPRESS) if counted else MAD32_PER_PROOF_MSM)
+                                   * value / world / PEAK_MAD32_PER_S,
+                "frac_whole_step_what": "counted MADs per proof of the MSM pair AND the decompression (the scalar kernels' mod-q multiplies are "
+                                        "not counted) x proofs/s per GPU / peak: the whole pipelined step as the timed region runs it; equals "
+                                        "value x 3.177e6 / peak, so it can be checked against the driver's own clock",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
