@@ -84,19 +84,15 @@ BP_HD xyzz ec_mul_glv(const affine& P, const fq& k, xyzz* tab) {
 // the base 2^68 * P_half).  The four slices of a point run in four lanes and are summed by the caller's lane tree:
 // the longest lane does 68 + 60 doublings and 16 additions instead of 128 doublings and 66 additions.
 #define ECMUL_SPLIT_W 17
-BP_HD xyzz ec_mul_glv_slice(const affine& P, const fq& k, int slice, xyzz* tab) {
-    if (affine_is_inf(P)) return xyzz_inf();
-    fq k1, k2;
-    bool n1, n2;
-    fq_glv_split(k, k1, n1, k2, n2);
+// The part of a slice that does not depend on the scalar: tab[i] = (i + 1) * base, base = 2^(4 w_lo) * P_half (68 doublings
+// for part 1).  The batch verifier builds these tables beside its scalar kernels (k_bpv_consts_pre), so that only
+// ec_slice_ladder is left once the scalars exist.  P must not be the point at infinity.
+BP_HD void ec_slice_table(const affine& P, int slice, xyzz* tab) {
     const int half = slice & 1, part = slice >> 1;
-    const fq kk = half ? k2 : k1;
-    const bool neg = half ? n2 : n1;
     affine Ph = P;
     if (half) Ph.x = fp_mul(P.x, fp_beta());
-    const int w_lo = part ? ECMUL_SPLIT_W : 0, w_hi = part ? ECMUL_WINS : ECMUL_SPLIT_W;
     xyzz base = xyzz_from_affine(Ph);
-    if (part) base = xyzz_dbl_n(base, 4 * w_lo);
+    if (part) base = xyzz_dbl_n(base, 4 * ECMUL_SPLIT_W);
     tab[0] = base;
     xyzz t = xyzz_dbl(base);
     tab[1] = t;
@@ -104,6 +100,16 @@ BP_HD xyzz ec_mul_glv_slice(const affine& P, const fq& k, int slice, xyzz* tab) 
         xyzz_add(t, base);
         tab[i] = t;
     }
+}
+// the slice's windows over a table made by ec_slice_table for the same (point, slice)
+BP_HD xyzz ec_slice_ladder(const fq& k, int slice, const xyzz* tab) {
+    fq k1, k2;
+    bool n1, n2;
+    fq_glv_split(k, k1, n1, k2, n2);
+    const int half = slice & 1, part = slice >> 1;
+    const fq kk = half ? k2 : k1;
+    const bool neg = half ? n2 : n1;
+    const int w_lo = part ? ECMUL_SPLIT_W : 0, w_hi = part ? ECMUL_WINS : ECMUL_SPLIT_W;
     const uint64_t cm = ecmul_carry_mask(kk);
     xyzz acc = xyzz_inf();
     for (int w = w_hi - 1; w >= w_lo; w--) {
@@ -116,6 +122,11 @@ BP_HD xyzz ec_mul_glv_slice(const affine& P, const fq& k, int slice, xyzz* tab) 
         }
     }
     return acc;
+}
+BP_HD xyzz ec_mul_glv_slice(const affine& P, const fq& k, int slice, xyzz* tab) {
+    if (affine_is_inf(P)) return xyzz_inf();
+    ec_slice_table(P, slice, tab);
+    return ec_slice_ladder(k, slice, tab);
 }
 
 // Interleaved (Straus) form for several points in ONE lane: sum_j k_j * P_j with a single chain of

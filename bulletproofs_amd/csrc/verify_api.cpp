@@ -387,17 +387,21 @@ static int verify_batch_launch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int
         HIPCHK(launch_bpv_decompress((const uint8_t*)d_proofs, proof_len, (const uint8_t*)d_coms_xy, k, m, nproofs, ws.pts, ws.bad, st),
                "bpv_decompress");
     prof_mark(ctx, 1);
+    // small batches: the ladders' scalar-independent window tables are built in the constants kernel's launch (into vartab)
+    const int lpp = bpv_small_fused(tp);
     if (wip)
         HIPCHK(launch_wipv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, ws.pts, gens->d_pts, gens->d_table, gens->c,
-                                           gens->W, ws.dig, nullptr, ws.var, d_chal, d_cst, d_fixres, d_fixaff, ws.bad, st, gens->ibase, (int)gens->nm),
+                                           gens->W, ws.dig, nullptr, ws.var, d_chal, d_cst, d_fixres, d_fixaff, ws.bad, st, gens->ibase, (int)gens->nm,
+                                           lpp ? ws.vartab : nullptr, lpp),
                "wipv_scalars");
     else
         HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, ws.pts, gens->d_pts, gens->d_table, gens->c,
-                                          gens->W, ws.dig, nullptr, ws.var, d_chal, d_cst, d_fixres, d_fixaff, ws.bad, st, gens->ibase, (int)gens->nm),
+                                          gens->W, ws.dig, nullptr, ws.var, d_chal, d_cst, d_fixres, d_fixaff, ws.bad, st, gens->ibase, (int)gens->nm,
+                                          lpp ? ws.vartab : nullptr, lpp),
                "bpv_scalars");
     prof_mark(ctx, 2);
     HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, ws.pts, gens->d_table, gens->c, gens->W, ws.dig, ws.var, ws.vartab, ws.fixpart, ws.bad,
-                          (uint8_t*)d_verdicts, st, wip, (int)gens->nm),
+                          (uint8_t*)d_verdicts, st, wip, (int)gens->nm, lpp ? 1 : 0),
            "bpv_msm");
     prof_mark(ctx, 3);
     if (ctx->profiling) {

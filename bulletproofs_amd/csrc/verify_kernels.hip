@@ -97,6 +97,51 @@ __global__ void k_wipv_decompress(const uint8_t* __restrict__ proofs, size_t pro
 #ifndef BPV_FIX_WAVES
 #define BPV_FIX_WAVES 3
 #endif
+// one lane's share of a proof's fixed-generator terms (terms lane, lane + TP, ...): table gathers + mixed additions
+template <int TP>
+__device__ __forceinline__ xyzz bpv_fix_lane_sum(int lane, int nm, const affine_mem* __restrict__ table, int c, int W, const tdig_t* __restrict__ dg,
+                                                 int shiftW) {
+    const int NB = 1 << (c - 1);
+    xyzz acc = xyzz_inf();
+    const int nfw = (2 * nm + 2) * W;
+    // shiftW != 0: the proof uses the first nm of the table's nm_tab generators per vector (a batch mixing aggregation
+    // sizes over one bp_gens): h_vec's rows start (nm_tab - nm) rows later, G and H twice that
+    const int hW = nm * W, gW = 2 * nm * W;
+    // Software pipeline, two terms per trip through two entry buffers (A, B): while term idx is added, the table entry of
+    // term idx + TP and the digit of term idx + 2 TP are in flight.  Every load is UNCONDITIONAL (a term past the end or a
+    // zero digit reads a valid dummy address and is masked at the addition): with loads inside `if (d != 0)` the number of
+    // loads in flight differed per path and the compiler fell back to s_waitcnt vmcnt(0) in front of every addition, which
+    // waited for the prefetch it had just issued (ISA of round 2's first version).  Measured on the 65 536-proof batch: no
+    // change (7.22 -> 7.24 ms) - at three waves per SIMD the other waves already covered the exposed gather; it is what a
+    // lone wave of a small batch needs.
+    auto digit = [&](int idx) { return (int)dg[idx < nfw ? idx : nfw - 1]; };
+    auto entry = [&](int idx, int d) {
+        const int i = idx < nfw ? idx : nfw - 1;
+        const int row = i + (i >= hW ? shiftW : 0) + (i >= gW ? shiftW : 0);
+        const int a = d < 0 ? -d : d;
+        return affine_mem_ld(table + (size_t)row * NB + (a ? a - 1 : 0));
+    };
+    auto add = [&](const affine_mem& m, int d, int idx) {
+        if (d != 0 && idx < nfw) {
+            affine e = affine_load(m);
+            xyzz_madd_s(acc, e, d < 0);
+        }
+    };
+    int dA = digit(lane), dB = digit(lane + TP);
+    affine_mem A = entry(lane, dA), B;
+    for (int idx = lane; idx < nfw; idx += 2 * TP) {
+        int dN = digit(idx + 2 * TP);
+        B = entry(idx + TP, dB);
+        add(A, dA, idx);
+        dA = dN;
+        dN = digit(idx + 3 * TP);
+        A = entry(idx + 2 * TP, dA);
+        add(B, dB, idx + TP);
+        dB = dN;
+    }
+    return acc;
+}
+
 template <int TP>
 __global__ __launch_bounds__(256, BPV_FIX_WAVES) void k_bpv_fix(int nm, size_t nproofs, const affine_mem* __restrict__ table, int c, int W,
                                                     const tdig_t* __restrict__ digF, const int* __restrict__ bad, int shiftW,
@@ -106,47 +151,8 @@ __global__ __launch_bounds__(256, BPV_FIX_WAVES) void k_bpv_fix(int nm, size_t n
     const int lane = tid % TP;
     const size_t pr = (size_t)blockIdx.x * (256 / TP) + tid / TP;
     const bool active = pr < nproofs && !bad[pr];
-    const int NB = 1 << (c - 1);
     xyzz acc = xyzz_inf();
-    if (active) {
-        const int nfw = (2 * nm + 2) * W;
-        const tdig_t* dg = digF + pr * (size_t)nfw;
-        // shiftW != 0: the proof uses the first nm of the table's nm_tab generators per vector (a batch mixing aggregation
-        // sizes over one bp_gens): h_vec's rows start (nm_tab - nm) rows later, G and H twice that
-        const int hW = nm * W, gW = 2 * nm * W;
-        // Software pipeline, two terms per trip through two entry buffers (A, B): while term idx is added, the table entry of
-        // term idx + TP and the digit of term idx + 2 TP are in flight.  Every load is UNCONDITIONAL (a term past the end or a
-        // zero digit reads a valid dummy address and is masked at the addition): with loads inside `if (d != 0)` the number of
-        // loads in flight differed per path and the compiler fell back to s_waitcnt vmcnt(0) in front of every addition, which
-        // waited for the prefetch it had just issued (ISA of round 2's first version).  Measured on the 65 536-proof batch: no
-        // change (7.22 -> 7.24 ms) - at three waves per SIMD the other waves already covered the exposed gather; it is what a
-        // lone wave of a small batch needs.
-        auto digit = [&](int idx) { return (int)dg[idx < nfw ? idx : nfw - 1]; };
-        auto entry = [&](int idx, int d) {
-            const int i = idx < nfw ? idx : nfw - 1;
-            const int row = i + (i >= hW ? shiftW : 0) + (i >= gW ? shiftW : 0);
-            const int a = d < 0 ? -d : d;
-            return affine_mem_ld(table + (size_t)row * NB + (a ? a - 1 : 0));
-        };
-        auto add = [&](const affine_mem& m, int d, int idx) {
-            if (d != 0 && idx < nfw) {
-                affine e = affine_load(m);
-                xyzz_madd_s(acc, e, d < 0);
-            }
-        };
-        int dA = digit(lane), dB = digit(lane + TP);
-        affine_mem A = entry(lane, dA), B;
-        for (int idx = lane; idx < nfw; idx += 2 * TP) {
-            int dN = digit(idx + 2 * TP);
-            B = entry(idx + TP, dB);
-            add(A, dA, idx);
-            dA = dN;
-            dN = digit(idx + 3 * TP);
-            A = entry(idx + 2 * TP, dA);
-            add(B, dB, idx + TP);
-            dB = dN;
-        }
-    }
+    if (active) acc = bpv_fix_lane_sum<TP>(lane, nm, table, c, W, digF + pr * (size_t)((2 * nm + 2) * W), shiftW);
     if (TP > 1) {
         red[tid] = acc;
         __syncthreads();
@@ -289,6 +295,69 @@ __global__ __launch_bounds__(256) void k_bpv_msm_slice(int m, int k, size_t npro
     }
 }
 
+// Small batches, both halves of the MSM in ONE launch: 2 * LPP lanes per proof - the first LPP run the slices of
+// k_bpv_msm_slice, the other LPP the fixed-generator terms of k_bpv_fix<LPP> - and one tree over all of them.  In a
+// latency-bound batch the two kernels ran one after the other on a mostly empty GPU (512 proofs: 197 us of table
+// additions, then 590 us of ladders); side by side the table additions disappear behind the ladders.  For LPP >= 64 the
+// two roles are whole waves; below that a wave runs both paths in turn (no gain, no loss against two launches).
+template <int LPP>
+__global__ __launch_bounds__(256) void k_bpv_small(int nm, int m, int k, size_t nproofs, const affine_mem* __restrict__ pts,
+                                                    const affine_mem* __restrict__ table, int c, int W, const tdig_t* __restrict__ digF, int shiftW,
+                                                    const fq* __restrict__ varS, xyzz* __restrict__ vartab, const int* __restrict__ bad,
+                                                    uint8_t* __restrict__ verdicts, int wip, int pre) {
+    static_assert(2 * LPP <= 256, "one proof fits a workgroup");
+    __shared__ xyzz red[256];
+    const int tid = threadIdx.x;
+    const int sub = tid % (2 * LPP), lane = sub % LPP;
+    const bool fixrole = sub >= LPP;
+    const size_t pr = (size_t)blockIdx.x * (256 / (2 * LPP)) + tid / (2 * LPP);
+    const bool active = pr < nproofs && !bad[pr];
+    const int NPT = (wip ? 3 : 4) + 2 * k + m;
+    const int NV = (wip ? 2 : 3) + 2 * k + m;
+    xyzz acc = xyzz_inf();
+    if (active) {
+        if (fixrole) {
+            acc = bpv_fix_lane_sum<LPP>(lane, nm, table, c, W, digF + pr * (size_t)((2 * nm + 2) * W), shiftW);
+        } else {
+            const affine_mem* P = pts + pr * NPT;
+            const fq* vs = varS + pr * (size_t)NV;
+            xyzz* tab = vartab + (pr * LPP + lane) * ECMUL_NT;
+            for (int idx = lane; idx < 4 * NV; idx += LPP) {
+                const int v = idx >> 2, slice = idx & 3;
+                // variable point order: S, L_0.., R_0.., V_0.., T1, T2  ->  index into pts (as in k_bpv_msm)
+                const int pi = wip ? 1 + v : (v == 0) ? 1 : (v < 1 + 2 * k + m) ? (3 + v) : (v == 1 + 2 * k + m ? 2 : 3);
+                // pre: the slice's window table was built beside the constants kernel (k_bpv_consts_pre, verify_scalars.hip)
+                const affine Pv = affine_load(P[pi]);
+                xyzz t = !pre ? ec_mul_glv_slice(Pv, vs[v], slice, tab) : affine_is_inf(Pv) ? xyzz_inf() : ec_slice_ladder(vs[v], slice, tab);
+                xyzz_add(acc, t);
+            }
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int off = LPP; off >= 1; off >>= 1) {
+        if (sub < off) {
+            xyzz v = red[tid];
+            xyzz o = red[tid + off];
+            xyzz_add(v, o);
+            red[tid] = v;
+        }
+        __syncthreads();
+    }
+    if (sub == 0 && pr < nproofs) {
+        uint8_t verdict;
+        if (bad[pr]) {
+            verdict = 255;
+        } else {
+            xyzz r = red[tid];
+            affine A = affine_load(pts[pr * NPT]);
+            bool eq = !xyzz_is_inf(r) && fp_eq(r.X, fp_mul(A.x, r.ZZ)) && fp_eq(r.Y, fp_mul(A.y, r.ZZZ));
+            verdict = eq ? 0 : 3;
+        }
+        verdicts[pr] = verdict;
+    }
+}
+
 hipError_t launch_bpv_decompress(const uint8_t* proofs, size_t proof_len, const uint8_t* coms_xy, int k, int m, size_t nproofs, affine_mem* pts,
                                  int* bad, hipStream_t st) {
     size_t total = nproofs * (size_t)(4 + 2 * k + m);
@@ -328,11 +397,31 @@ static int bpv_fix_lanes(int tp, size_t nproofs, int nm) {
     while (tf > 2 && tf > 2 * nm + 2) tf /= 2;
     return tf;
 }
+int bpv_small_fused(int tp) {
+    static const bool split = getenv("BP_VERIFY_SMALL_SPLIT") != nullptr;  // A/B: the two-launch form
+    return (tp < 0 && -tp <= 128 && !split) ? -tp : 0;
+}
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
                           const tdig_t* digF, const fq* varS, xyzz* vartab, xyzz* fixpart, const int* bad, uint8_t* verdicts, hipStream_t st,
-                          int wip, int nm_tab) {
+                          int wip, int nm_tab, int pre) {
     const int nm = n_bits * m;
     const int shiftW = nm_tab > nm ? (nm_tab - nm) * W : 0;
+    if (const int lpp = bpv_small_fused(tp)) {  // small batch: table additions and ladders in one launch
+        const unsigned blocks = (unsigned)((nproofs + (256 / (2 * lpp)) - 1) / (256 / (2 * lpp)));
+#define BPV_SMALL(LPP)                                                                                                                         \
+    hipLaunchKernelGGL((k_bpv_small<LPP>), dim3(blocks), dim3(256), 0, st, nm, m, k, nproofs, pts, table, c, W, digF, shiftW, varS, vartab, bad, \
+                       verdicts, wip, pre)
+        if (lpp == 16)
+            BPV_SMALL(16);
+        else if (lpp == 32)
+            BPV_SMALL(32);
+        else if (lpp == 64)
+            BPV_SMALL(64);
+        else
+            BPV_SMALL(128);
+#undef BPV_SMALL
+        return hipGetLastError();
+    }
     const int tf = bpv_fix_lanes(tp < 0 ? 16 : tp, nproofs, nm);
     unsigned fblocks = (unsigned)((nproofs + (256 / tf) - 1) / (256 / tf));
 #define BPV_FIX(TP) hipLaunchKernelGGL((k_bpv_fix<TP>), dim3(fblocks), dim3(256), 0, st, nm, nproofs, table, c, W, digF, bad, shiftW, fixpart)

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ec.h"
+#include "ecmul.h"
 #include "fq.h"
 #include "kernels.h"
 #include "sha256.h"
@@ -351,10 +352,9 @@ __device__ __forceinline__ void bpv_split_tables(fqm* cs, int k, int m) {
     }
 }
 
-__global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
-                                                   const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF, fqm* __restrict__ scF,
-                                                   fq* __restrict__ varS, fqm* __restrict__ cst, int* __restrict__ bad) {
-    size_t pr = (size_t)blockIdx.x * 64 + threadIdx.x;
+__device__ __forceinline__ void bpv_consts_body(size_t pr, const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k,
+                                                size_t nproofs, const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF,
+                                                fqm* __restrict__ scF, fq* __restrict__ varS, fqm* __restrict__ cst, int* __restrict__ bad) {
     if (pr >= nproofs || bad[pr]) return;
     const int nm = n_bits * m;
     const int NV = 3 + 2 * k + m;
@@ -457,6 +457,12 @@ __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ p
     bpv_split_tables(cs, k, m);
 }
 
+__global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
+                                                   const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF, fqm* __restrict__ scF,
+                                                   fq* __restrict__ varS, fqm* __restrict__ cst, int* __restrict__ bad) {
+    bpv_consts_body((size_t)blockIdx.x * 64 + threadIdx.x, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W, digF, scF, varS, cst, bad);
+}
+
 // One lane per (proof, i): g_i : a s_i + z ; h_i : y^-i (b s_i^-1 - d_i) - z          :670-705
 // s_i = prod_t (bit_t(i) ? x_{k-1-t} : x_{k-1-t}^-1), s_i^-1 = s_{nm-1-i}; d_i = z^(2+i/n) 2^(i mod n).
 // Bulletproofs+ (wip != 0, range_proof_wip.rs:537-557) with the constants of k_wipv_consts:
@@ -505,17 +511,28 @@ size_t bpv_chal_count(int k) { return CH_COUNT(k); }
 // in units of sizeof(fq): the constants are stored as fqm (9 words)
 size_t bpv_cst_count(int k, int m) { return ((size_t)CS_COUNT(k, m) * sizeof(fqm) + sizeof(fq) - 1) / sizeof(fq); }
 
+// the constants kernel + the small-batch ladders' window tables in one launch (defined with the Bulletproofs+ kernels below)
+template <int WIP>
+__global__ void k_bpv_consts_pre(unsigned cblocks, const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
+                                 const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF, fqm* __restrict__ scF, fq* __restrict__ varS,
+                                 fqm* __restrict__ cst, int* __restrict__ bad, const affine_mem* __restrict__ pts, xyzz* __restrict__ pretab, int lpp);
 hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
                                       const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fqm* scF, fq* varS, fq* chal,
-                                      fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st, int ibase, int nm_tab) {
+                                      fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st, int ibase, int nm_tab, xyzz* pretab,
+                                      int lpp) {
     const int nm = n_bits * m;
     hipLaunchKernelGGL(k_bpv_hash1, dim3((unsigned)((nproofs * 4 + 63) / 64)), dim3(64), 0, st, proofs, proof_len, k, m, nm_tab, nproofs, pts, gens,
                        chal, bad);  // nm_tab: G, H sit after the table's nm_tab-long vectors (>= nm: the proof uses their prefixes)
     hipLaunchKernelGGL(k_bpv_fixmul, dim3((unsigned)((nproofs + 256 / (2 * FM_SUB) - 1) / (256 / (2 * FM_SUB)))), dim3(256), 0, st, k, nm_tab, nproofs, table, c, W, chal, fixres, bad, 2, ibase);
     hipLaunchKernelGGL(k_bpv_fixinv, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, nproofs, fixres, fixaff, bad);
     hipLaunchKernelGGL(k_bpv_hash2, dim3((unsigned)((nproofs * (k + 1) + 63) / 64)), dim3(64), 0, st, k, m, nproofs, pts, fixaff, chal, bad);
-    hipLaunchKernelGGL(k_bpv_consts, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W,
-                       digF, scF, varS, reinterpret_cast<fqm*>(cst), bad);
+    const unsigned cblocks = (unsigned)((nproofs + 63) / 64);
+    if (pretab && lpp > 0)  // + the ladders' window tables in the same launch (k_bpv_consts_pre)
+        hipLaunchKernelGGL((k_bpv_consts_pre<0>), dim3(cblocks + (unsigned)((nproofs * (size_t)lpp + 63) / 64)), dim3(64), 0, st, cblocks, proofs,
+                           proof_len, n_bits, m, k, nproofs, chal, c, W, digF, scF, varS, reinterpret_cast<fqm*>(cst), bad, pts, pretab, lpp);
+    else
+        hipLaunchKernelGGL(k_bpv_consts, dim3(cblocks), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W, digF, scF, varS,
+                           reinterpret_cast<fqm*>(cst), bad);
     hipLaunchKernelGGL(k_bpv_vec, dim3((unsigned)((nproofs * (size_t)nm + 255) / 256)), dim3(256), 0, st, n_bits, m, k, nproofs,
                        reinterpret_cast<const fqm*>(cst), c, W, digF, scF, bad, 0);
     return hipGetLastError();
@@ -598,10 +615,9 @@ __global__ __launch_bounds__(64) void k_wipv_hash2(int k, int m, size_t nproofs,
     chal[pr * CH_COUNT(k) + CH_Z] = msg_result_scalar(buf, pos);
 }
 
-__global__ __launch_bounds__(64) void k_wipv_consts(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
-                                                    const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF, fqm* __restrict__ scF,
-                                                    fq* __restrict__ varS, fqm* __restrict__ cst, int* __restrict__ bad) {
-    size_t pr = (size_t)blockIdx.x * 64 + threadIdx.x;
+__device__ __forceinline__ void wipv_consts_body(size_t pr, const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k,
+                                                 size_t nproofs, const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF,
+                                                 fqm* __restrict__ scF, fq* __restrict__ varS, fqm* __restrict__ cst, int* __restrict__ bad) {
     if (pr >= nproofs || bad[pr]) return;
     const int nm = n_bits * m;
     const int NV = 2 + 2 * k + m;
@@ -699,9 +715,48 @@ __global__ __launch_bounds__(64) void k_wipv_consts(const uint8_t* __restrict__ 
     bpv_split_tables(cs, k, m);
 }
 
+__global__ __launch_bounds__(64) void k_wipv_consts(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
+                                                    const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF, fqm* __restrict__ scF,
+                                                    fq* __restrict__ varS, fqm* __restrict__ cst, int* __restrict__ bad) {
+    wipv_consts_body((size_t)blockIdx.x * 64 + threadIdx.x, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W, digF, scF, varS, cst, bad);
+}
+
+// Small batches (k_bpv_small, verify_kernels.hip): the constants kernel and, IN THE SAME LAUNCH, the scalar-independent part of
+// the proof-specific ladders.  One lane per proof leaves the GPU empty for the length of the constants' serial chain
+// (0.16 ms); workgroups cblocks.. of this launch build, meanwhile, the window table of every (point, slice) lane of
+// k_bpv_small - for the upper slices that includes the 68 doublings of their base - so that only the windows themselves
+// are left once the scalars exist (512 proofs: 1.12 -> 0.9 ms per call).  Two roles in one launch rather than two
+// streams: a process has four hardware queues and the context's side stream carries the other batch in flight.
+template <int WIP>
+__global__ __launch_bounds__(64) void k_bpv_consts_pre(unsigned cblocks, const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k,
+                                                       size_t nproofs, const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF,
+                                                       fqm* __restrict__ scF, fq* __restrict__ varS, fqm* __restrict__ cst, int* __restrict__ bad,
+                                                       const affine_mem* __restrict__ pts, xyzz* __restrict__ pretab, int lpp) {
+    if (blockIdx.x < cblocks) {
+        const size_t pr = (size_t)blockIdx.x * 64 + threadIdx.x;
+        if (WIP)
+            wipv_consts_body(pr, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W, digF, scF, varS, cst, bad);
+        else
+            bpv_consts_body(pr, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W, digF, scF, varS, cst, bad);
+        return;
+    }
+    const size_t g = (size_t)(blockIdx.x - cblocks) * 64 + threadIdx.x;
+    const size_t pr = g / (size_t)lpp;
+    const int idx = (int)(g % (size_t)lpp);  // one (point, slice) per lane: lpp >= 4 NV (bpv_slice_lanes)
+    const int NPT = (WIP ? 3 : 4) + 2 * k + m, NV = (WIP ? 2 : 3) + 2 * k + m;
+    if (pr >= nproofs || idx >= 4 * NV) return;
+    const int v = idx >> 2, slice = idx & 3;
+    // variable point order: S, L_0.., R_0.., V_0.., T1, T2  ->  index into pts (as in k_bpv_msm)
+    const int pi = WIP ? 1 + v : (v == 0) ? 1 : (v < 1 + 2 * k + m) ? (3 + v) : (v == 1 + 2 * k + m ? 2 : 3);
+    const affine P = affine_load(pts[pr * NPT + pi]);
+    if (affine_is_inf(P)) return;  // (a malformed proof's slot: its verdict never reads the table)
+    ec_slice_table(P, slice, pretab + (pr * (size_t)lpp + idx) * ECMUL_NT);
+}
+
 hipError_t launch_wipv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
                                        const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fqm* scF, fq* varS, fq* chal,
-                                       fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st, int ibase, int nm_tab) {
+                                       fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st, int ibase, int nm_tab, xyzz* pretab,
+                                       int lpp) {
     const int nm = n_bits * m;
     hipLaunchKernelGGL(k_wipv_hash1, dim3((unsigned)((nproofs * (k + 2) + 63) / 64)), dim3(64), 0, st, proofs, proof_len, k, m, nm_tab, nproofs, pts,
                        gens, chal, bad);
@@ -709,8 +764,13 @@ hipError_t launch_wipv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, 
                        table, c, W, chal, fixres, bad, 1, ibase);
     hipLaunchKernelGGL(k_wipv_fixinv, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, nproofs, fixres, fixaff, bad);
     hipLaunchKernelGGL(k_wipv_hash2, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, k, m, nproofs, pts, fixaff, chal, bad);
-    hipLaunchKernelGGL(k_wipv_consts, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W,
-                       digF, scF, varS, reinterpret_cast<fqm*>(cst), bad);
+    const unsigned cblocks = (unsigned)((nproofs + 63) / 64);
+    if (pretab && lpp > 0)
+        hipLaunchKernelGGL((k_bpv_consts_pre<1>), dim3(cblocks + (unsigned)((nproofs * (size_t)lpp + 63) / 64)), dim3(64), 0, st, cblocks, proofs,
+                           proof_len, n_bits, m, k, nproofs, chal, c, W, digF, scF, varS, reinterpret_cast<fqm*>(cst), bad, pts, pretab, lpp);
+    else
+        hipLaunchKernelGGL(k_wipv_consts, dim3(cblocks), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W, digF, scF, varS,
+                           reinterpret_cast<fqm*>(cst), bad);
     hipLaunchKernelGGL(k_bpv_vec, dim3((unsigned)((nproofs * (size_t)nm + 255) / 256)), dim3(256), 0, st, n_bits, m, k, nproofs,
                        reinterpret_cast<const fqm*>(cst), c, W, digF, scF, bad, 1);
     return hipGetLastError();
