@@ -481,3 +481,42 @@ def test_overlapped_device_calls_match_the_serial_form(ctx):
     finally:
         ctx.set_verify_overlap(1)
         gens.close()
+
+
+def test_overlapped_bpplus_and_bp_calls_interleaved(ctx):
+    """Bulletproofs+ and Bulletproofs device calls alternating on one context with no sync in between (so consecutive calls
+    of DIFFERENT protocols, generator tables and shapes sit on the two lanes at once): the golden verdicts, overlap on
+    and off."""
+    import torch
+    from _golden import bpplus_cases
+    dev = torch.device("cuda", 0)
+    plus = bpplus_cases()[1]
+    bp = bp_cases()[2]
+    gens_p, _, _ = _plus_gens(ctx, plus["n"], plus["m"])
+    gens_b = _gens(ctx, bp["n"], bp["m"], 8)
+    try:
+        pp, pc, pw = _case_batch(plus)
+        bp_proofs, bp_coms, bw = _case_batch(bp)
+        reps = 7
+        jobs = []
+        for r in range(6):
+            for (fn, gens, case, proofs, coms, want) in ((ctx.wip_rangeproof_verify_batch_device, gens_p, plus, pp, pc, pw),
+                                                         (ctx.rangeproof_verify_batch_device, gens_b, bp, bp_proofs, bp_coms, bw)):
+                k = reps + r
+                d_p = torch.frombuffer(bytearray(b"".join(proofs) * k), dtype=torch.uint8).to(dev)
+                d_c = torch.frombuffer(bytearray(b"".join(coms) * k), dtype=torch.uint8).to(dev)
+                jobs.append((fn, gens, case["n"], case["m"], d_p, len(proofs[0]), d_c, len(proofs) * k, want * k))
+        torch.cuda.synchronize()
+        for overlap in (1, 0):
+            ctx.set_verify_overlap(overlap)
+            outs = [torch.full((j[7],), 77, dtype=torch.uint8, device=dev) for j in jobs]
+            torch.cuda.synchronize()
+            for (fn, gens, n, m, d_p, plen, d_c, cnt, want), o in zip(jobs, outs):
+                fn(gens, n, m, d_p.data_ptr(), plen, d_c.data_ptr(), cnt, o.data_ptr())
+            ctx.sync()
+            for (fn, gens, n, m, d_p, plen, d_c, cnt, want), o in zip(jobs, outs):
+                assert o.cpu().tolist() == want
+    finally:
+        ctx.set_verify_overlap(1)
+        gens_p.close()
+        gens_b.close()
