@@ -8,10 +8,13 @@
 //                      650-668) with SHA-256 on device, the two fixed-base multiplications y*G and
 //                      x_u*G (:571, :588) from the generator table, then the whole scalar vector of
 //                      :670-740 in Montgomery arithmetic mod q, recoded to signed window digits.
-//   k_bpv_msm        : TP lanes per proof.  The MSM of :742-774: fixed generators via table gathers
-//                      (no doublings), proof-specific points (S, L_j, R_j, V_j, T1, T2) via GLV +
+//   k_bpv_fix        : the 2nm+2 fixed-generator terms of the MSM of :742-774: table gathers + mixed additions, no
+//                      doublings; one partial sum per proof.
+//   k_bpv_msm        : TP lanes per proof.  The proof-specific points (S, L_j, R_j, V_j, T1, T2) via GLV +
 //                      interleaved 4-bit windows (ecmul.h: lanes that own several points share one
-//                      doubling chain), lane-tree reduction, and the comparison with A (:777).
+//                      doubling chain), lane-tree reduction, + the fixed partial, and the comparison with A (:777).
+//   k_bpv_small      : latency-bound batches (up to ~1024 proofs): both halves in one launch, four lanes per
+//                      proof-specific point (k_bpv_msm_slice is its two-launch form for shapes beyond 128 such lanes).
 //
 // Per-proof verdicts follow `Result<(), Errors>`: 0 = Ok, 3 = RangeProofError, 255 = the proof bytes
 // would not deserialize in the reference (bad point / scalar >= q / zero challenge).
