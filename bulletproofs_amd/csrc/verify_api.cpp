@@ -154,6 +154,7 @@ static int gens_create_locked(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h
 void bp_gens_destroy(bp_gens* g) {
     if (!g) return;
     (void)hipSetDevice(g->device);
+    (void)hipDeviceSynchronize();  // asynchronous verifications of any context may still be reading the table
     if (g->d_pts) (void)hipFree(g->d_pts);
     if (g->d_table) (void)hipFree(g->d_table);
     delete g;
