@@ -414,6 +414,8 @@ void bp_ctx_destroy(bp_ctx* ctx) {
         (void)hipStreamDestroy(ctx->vside);
     }
     if (ctx->v_ev_side) (void)hipEventDestroy(ctx->v_ev_side);
+    if (ctx->v_ev_fork) (void)hipEventDestroy(ctx->v_ev_fork);
+    if (ctx->v_ev_join) (void)hipEventDestroy(ctx->v_ev_join);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

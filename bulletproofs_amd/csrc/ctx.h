@@ -60,6 +60,7 @@ struct bp_ctx {
         return hipSuccess;
     }
     hipEvent_t v_ev_side = nullptr;
+    hipEvent_t v_ev_fork = nullptr, v_ev_join = nullptr;  // one call alone: k_bpv_fix on the side stream beside the proof-specific kernel
     bool v_side_pending = false;
     unsigned v_calls = 0;
     bp::DevBuf vws[8];

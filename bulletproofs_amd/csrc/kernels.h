@@ -78,7 +78,8 @@ hipError_t launch_rlc_colsum(int np, size_t nproofs, const fqm* rho, const fqm* 
 hipError_t launch_rlc_verdicts(size_t nproofs, const uint8_t* result_be, const int* bad, uint8_t* verdicts, int* all_ok, hipStream_t st);
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
                           const tdig_t* digF, const fq* varS, xyzz* vartab, xyzz* fixpart, const int* bad, uint8_t* verdicts, hipStream_t st,
-                          int wip = 0, int nm_tab = 0, int pre = 0);  // pre: vartab already holds the slices' window tables
+                          int wip = 0, int nm_tab = 0, int pre = 0,  // pre: vartab already holds the slices' window tables
+                          hipStream_t helper = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);  // helper: stream for k_bpv_fix
 size_t bpv_msm_fixpart_bytes(size_t nproofs);
 // lanes per proof (> 0) when a batch with tp lanes takes the one-launch small-batch MSM (k_bpv_small) and its window tables
 // are built beside the constants kernel (k_bpv_consts_pre); 0 otherwise

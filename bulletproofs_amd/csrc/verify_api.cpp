@@ -192,6 +192,7 @@ int bp_ctx_sync(bp_ctx* ctx) {
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     if (ctx->vside) HIPCHK(hipStreamSynchronize(ctx->vside), "sync");
     ctx->v_side_pending = false;
+    ctx->v_calls = 0;  // the next call is one call alone again: on the context's stream, its table kernel on the side stream
     HIPCHK(hipStreamSynchronize(ctx->stream), "sync");
     if (ctx->profiling) prof_collect(ctx);
     return BP_OK;
@@ -304,7 +305,8 @@ static VerifySizes verify_ws_sizes(const bp_ctx* ctx, const bp_gens* gens, int n
 }
 
 static int verify_batch_launch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, const void* d_proofs, size_t proof_len,
-                               const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip, const VerifyWs& ws, int tp, hipStream_t st);
+                               const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip, const VerifyWs& ws, int tp, hipStream_t st,
+                               bool use_helper = false);
 static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, const void* d_proofs, size_t proof_len,
                                       const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip = 0, bool overlap = false);
 
@@ -323,6 +325,8 @@ static int verify_overlap_init(bp_ctx* ctx) {
     hipStream_t s;
     HIPCHK(ctx->side_stream(&s), "hipStreamCreate");
     HIPCHK(hipEventCreateWithFlags(&ctx->v_ev_side, hipEventDisableTiming), "hipEventCreate");
+    HIPCHK(hipEventCreateWithFlags(&ctx->v_ev_fork, hipEventDisableTiming), "hipEventCreate");
+    HIPCHK(hipEventCreateWithFlags(&ctx->v_ev_join, hipEventDisableTiming), "hipEventCreate");
     return BP_OK;
 }
 
@@ -346,6 +350,14 @@ static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bi
     } else {
         ctx->join_side();  // a serial call after overlapped ones (overlap switched off, per-stage timing switched on)
     }
+    // One call ALONE (nothing pending on the side lane: a synchronous caller, or the first call of a stream of calls): its
+    // fixed-generator kernel goes to the side stream, beside the proof-specific kernel (launch_bpv_msm).  Not under per-stage
+    // timing, whose figures are the kernels with the GPU to themselves.
+    bool use_helper = false;
+    if (!side && !ctx->v_side_pending && ctx->verify_overlap && !ctx->profiling) {
+        if ((rc = verify_overlap_init(ctx)) != BP_OK) return rc;
+        use_helper = true;
+    }
     DevBuf* w = side ? ctx->vws : nullptr;
     DevBuf &b_pts = w ? w[0] : ctx->scratch[0], &b_bad = w ? w[1] : ctx->scratch[1], &b_dig = w ? w[2] : ctx->scratch[2],
            &b_var = w ? w[3] : ctx->scratch[3], &b_s = w ? w[4] : ctx->scratch[4], &b_fixres = w ? w[5] : ctx->fixres,
@@ -360,7 +372,8 @@ static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bi
     if ((rc = b_fixpart.reserve(z.fixpart)) != BP_OK) return rc;
     VerifyWs ws{(affine_mem*)b_pts.p, (int*)b_bad.p, (tdig_t*)b_dig.p, (fq*)b_var.p, (fq*)b_s.p, (xyzz*)b_fixres.p, (xyzz*)b_vartab.p,
                 (xyzz*)b_fixpart.p};
-    rc = verify_batch_launch(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, wip, ws, z.tp, side ? ctx->vside : ctx->stream);
+    rc = verify_batch_launch(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, wip, ws, z.tp, side ? ctx->vside : ctx->stream,
+                             use_helper);
     if (side) {
         HIPCHK(hipEventRecord(ctx->v_ev_side, ctx->vside), "record event");
         ctx->v_side_pending = true;
@@ -370,7 +383,8 @@ static int verify_batch_device_nolock(bp_ctx* ctx, const bp_gens* gens, int n_bi
 
 // the kernels of one batch verification on stream st (the context's, or the side lane's); allocates nothing
 static int verify_batch_launch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, int k, const void* d_proofs, size_t proof_len,
-                               const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip, const VerifyWs& ws, int tp, hipStream_t st) {
+                               const void* d_coms_xy, size_t nproofs, void* d_verdicts, int wip, const VerifyWs& ws, int tp, hipStream_t st,
+                               bool use_helper) {
     fq* d_chal = ws.chal;
     fq* d_cst = d_chal + nproofs * bpv_chal_count(k);
     xyzz* d_fixres = ws.fixres;
@@ -402,7 +416,8 @@ static int verify_batch_launch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int
                "bpv_scalars");
     prof_mark(ctx, 2);
     HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, ws.pts, gens->d_table, gens->c, gens->W, ws.dig, ws.var, ws.vartab, ws.fixpart, ws.bad,
-                          (uint8_t*)d_verdicts, st, wip, (int)gens->nm, lpp ? 1 : 0),
+                          (uint8_t*)d_verdicts, st, wip, (int)gens->nm, lpp ? 1 : 0, use_helper ? ctx->vside : nullptr, ctx->v_ev_fork,
+                          ctx->v_ev_join),
            "bpv_msm");
     prof_mark(ctx, 3);
     if (ctx->profiling) {

@@ -184,7 +184,9 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
                                                  const xyzz* __restrict__ fixpart,
                                                  const fq* __restrict__ varS, xyzz* __restrict__ vartab, affine_mem* __restrict__ varaff,
                                                  int8_t* __restrict__ vardig, const int* __restrict__ bad, uint8_t* __restrict__ verdicts,
-                                                 int wip) {
+                                                 int wip, xyzz* __restrict__ varpart) {
+    // varpart != nullptr: k_bpv_fix runs BESIDE this kernel on the helper stream (launch_bpv_msm), so the sum does not start from
+    // fixpart[pr]; the proof-specific sum alone goes to varpart[pr] and k_bpv_verdict finishes
     __shared__ xyzz red[256];
     const int tid = threadIdx.x;
     const int lane = tid % TP;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
     const int NV = (wip ? 2 : 3) + 2 * k + m;
     xyzz acc = xyzz_inf();
     if (active) {
-        if (lane == 0) acc = fixpart[pr];  // the fixed-generator half, summed by k_bpv_fix
+        if (lane == 0 && !varpart) acc = fixpart[pr];  // the fixed-generator half, summed by k_bpv_fix
         const affine_mem* P = pts + pr * NPT;
         const fq* vs = varS + pr * (size_t)NV;
         const size_t gl = (size_t)blockIdx.x * 256 + tid;
@@ -228,7 +230,9 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
         }
         __syncthreads();
     }
-    if (lane == 0 && pr < nproofs) {
+    if (lane == 0 && pr < nproofs && varpart) {
+        varpart[pr] = red[tid];
+    } else if (lane == 0 && pr < nproofs) {
         uint8_t verdict;
         if (bad[pr]) {
             verdict = 255;
@@ -251,7 +255,8 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
 template <int LPP>
 __global__ __launch_bounds__(256) void k_bpv_msm_slice(int m, int k, size_t nproofs, const affine_mem* __restrict__ pts,
                                                         const xyzz* __restrict__ fixpart, const fq* __restrict__ varS, xyzz* __restrict__ vartab,
-                                                        const int* __restrict__ bad, uint8_t* __restrict__ verdicts, int wip) {
+                                                        const int* __restrict__ bad, uint8_t* __restrict__ verdicts, int wip,
+                                                        xyzz* __restrict__ varpart) {  // varpart: as in k_bpv_msm
     __shared__ xyzz red[256];
     const int tid = threadIdx.x;
     const int lane = tid % LPP;
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256) void k_bpv_msm_slice(int m, int k, size_t npro
     const int NV = (wip ? 2 : 3) + 2 * k + m;
     xyzz acc = xyzz_inf();
     if (active) {
-        if (lane == 0) acc = fixpart[pr];
+        if (lane == 0 && !varpart) acc = fixpart[pr];
         const affine_mem* P = pts + pr * NPT;
         const fq* vs = varS + pr * (size_t)NV;
         xyzz* tab = vartab + ((size_t)blockIdx.x * 256 + tid) * ECMUL_NT;
@@ -284,7 +289,9 @@ __global__ __launch_bounds__(256) void k_bpv_msm_slice(int m, int k, size_t npro
         }
         __syncthreads();
     }
-    if (lane == 0 && pr < nproofs) {
+    if (lane == 0 && pr < nproofs && varpart) {
+        varpart[pr] = red[tid];
+    } else if (lane == 0 && pr < nproofs) {
         uint8_t verdict;
         if (bad[pr]) {
             verdict = 255;
@@ -296,6 +303,26 @@ __global__ __launch_bounds__(256) void k_bpv_msm_slice(int m, int k, size_t npro
         }
         verdicts[pr] = verdict;
     }
+}
+
+// verdict of a proof from the two partial sums when k_bpv_fix ran beside the proof-specific kernel: fixpart + varpart == A ?
+// (range_proof.rs:777; == b_tag, range_proof_wip.rs:604)
+__global__ __launch_bounds__(256) void k_bpv_verdict(int m, int k, size_t nproofs, const affine_mem* __restrict__ pts, const xyzz* __restrict__ fixpart,
+                                                     const xyzz* __restrict__ varpart, const int* __restrict__ bad, uint8_t* __restrict__ verdicts,
+                                                     int wip) {
+    const size_t pr = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pr >= nproofs) return;
+    if (bad[pr]) {
+        verdicts[pr] = 255;
+        return;
+    }
+    const int NPT = (wip ? 3 : 4) + 2 * k + m;
+    xyzz r = fixpart[pr];
+    xyzz v = varpart[pr];
+    xyzz_add(r, v);
+    affine A = affine_load(pts[pr * NPT]);
+    bool eq = !xyzz_is_inf(r) && fp_eq(r.X, fp_mul(A.x, r.ZZ)) && fp_eq(r.Y, fp_mul(A.y, r.ZZZ));
+    verdicts[pr] = eq ? 0 : 3;
 }
 
 // Small batches, both halves of the MSM in ONE launch: 2 * LPP lanes per proof - the first LPP run the slices of
@@ -392,7 +419,7 @@ size_t bpv_msm_vartab_bytes(int tp, size_t nproofs) {
     size_t blocks = (nproofs + (256 / tp) - 1) / (256 / tp);
     return blocks * 256 * bpv_ppl(tp) * (ECMUL_SLOTS * sizeof(xyzz) + ECMUL_NT * sizeof(affine_mem) + ECMUL_DIGB);
 }
-size_t bpv_msm_fixpart_bytes(size_t nproofs) { return nproofs * sizeof(xyzz); }
+size_t bpv_msm_fixpart_bytes(size_t nproofs) { return 2 * nproofs * sizeof(xyzz); }  // fixed-generator sums | proof-specific sums (helper-stream form)
 // lanes per proof of the fixed-generator kernel: enough for 4 waves on every SIMD (262144 lanes) when the batch allows
 static int bpv_fix_lanes(int tp, size_t nproofs, int nm) {
     int tf = tp < 4 ? 4 : tp;
@@ -406,7 +433,7 @@ int bpv_small_fused(int tp) {
 }
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
                           const tdig_t* digF, const fq* varS, xyzz* vartab, xyzz* fixpart, const int* bad, uint8_t* verdicts, hipStream_t st,
-                          int wip, int nm_tab, int pre) {
+                          int wip, int nm_tab, int pre, hipStream_t helper, hipEvent_t ev_fork, hipEvent_t ev_join) {
     const int nm = n_bits * m;
     const int shiftW = nm_tab > nm ? (nm_tab - nm) * W : 0;
     if (const int lpp = bpv_small_fused(tp)) {  // small batch: table additions and ladders in one launch
@@ -427,7 +454,18 @@ hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, cons
     }
     const int tf = bpv_fix_lanes(tp < 0 ? 16 : tp, nproofs, nm);
     unsigned fblocks = (unsigned)((nproofs + (256 / tf) - 1) / (256 / tf));
-#define BPV_FIX(TP) hipLaunchKernelGGL((k_bpv_fix<TP>), dim3(fblocks), dim3(256), 0, st, nm, nproofs, table, c, W, digF, bad, shiftW, fixpart)
+    // helper != nullptr: the fixed-generator kernel on the helper stream BESIDE the proof-specific kernel (one call alone leaves
+    // room for both: 65 536 proofs 13.2 -> ~12 ms for the pair, 4096 proofs 1.64 -> ~1.0 ms); the sums meet in k_bpv_verdict
+    hipStream_t sf = st;
+    xyzz* varpart = nullptr;
+    if (helper) {
+        hipError_t e;
+        if ((e = hipEventRecord(ev_fork, st)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(helper, ev_fork, 0)) != hipSuccess) return e;
+        sf = helper;
+        varpart = fixpart + nproofs;
+    }
+#define BPV_FIX(TP) hipLaunchKernelGGL((k_bpv_fix<TP>), dim3(fblocks), dim3(256), 0, sf, nm, nproofs, table, c, W, digF, bad, shiftW, fixpart)
     if (tf == 4)
         BPV_FIX(4);
     else if (tf == 8)
@@ -441,10 +479,22 @@ hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, cons
     else
         BPV_FIX(2);
 #undef BPV_FIX
+    if (helper) {
+        hipError_t e;
+        if ((e = hipEventRecord(ev_join, helper)) != hipSuccess) return e;
+    }
+    auto finish = [&]() -> hipError_t {  // after the proof-specific kernel
+        if (!helper) return hipGetLastError();
+        hipError_t e;
+        if ((e = hipStreamWaitEvent(st, ev_join, 0)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_bpv_verdict, dim3((unsigned)((nproofs + 255) / 256)), dim3(256), 0, st, m, k, nproofs, pts, fixpart, varpart, bad, verdicts,
+                           wip);
+        return hipGetLastError();
+    };
     if (tp < 0) {
         const int lpp = -tp;
         unsigned sblocks = (unsigned)((nproofs * (size_t)lpp + 255) / 256);
-#define BPV_SLICE(LPP) hipLaunchKernelGGL((k_bpv_msm_slice<LPP>), dim3(sblocks), dim3(256), 0, st, m, k, nproofs, pts, fixpart, varS, vartab, bad, verdicts, wip)
+#define BPV_SLICE(LPP) hipLaunchKernelGGL((k_bpv_msm_slice<LPP>), dim3(sblocks), dim3(256), 0, st, m, k, nproofs, pts, fixpart, varS, vartab, bad, verdicts, wip, varpart)
         if (lpp == 16)
             BPV_SLICE(16);
         else if (lpp == 32)
@@ -456,7 +506,7 @@ hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, cons
         else
             BPV_SLICE(256);
 #undef BPV_SLICE
-        return hipGetLastError();
+        return finish();
     }
     unsigned blocks = (unsigned)((nproofs + (256 / tp) - 1) / (256 / tp));
     // vartab = [XYZZ construction slots | finished 64-byte tables | digits], each per lane
@@ -464,7 +514,7 @@ hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, cons
     int8_t* vardig = reinterpret_cast<int8_t*>(varaff + (size_t)blocks * 256 * bpv_ppl(tp) * ECMUL_NT);
 #define BPV_LAUNCH(TP, PPL)                                                                                                                  \
     hipLaunchKernelGGL((k_bpv_msm<TP, PPL>), dim3(blocks), dim3(256), 0, st, n_bits, m, k, nproofs, pts, fixpart, varS, vartab, varaff, vardig, bad, \
-                       verdicts, wip)
+                       verdicts, wip, varpart)
     if (tp == 2)
         BPV_LAUNCH(2, 8);
     else if (tp == 4)
@@ -478,7 +528,7 @@ hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, cons
     else
         BPV_LAUNCH(64, 1);
 #undef BPV_LAUNCH
-    return hipGetLastError();
+    return finish();
 }
 
 }  // namespace bp

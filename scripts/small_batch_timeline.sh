@@ -14,7 +14,7 @@ gens = bpa.Gens(ctx, g_xy, h_xy, G_xy, H_xy, 0)
 proofs, coms, plen = bench.make_distinct_batch(ctx, gens, G_xy, H_xy, 0, 1, P, b"sb")
 dp = torch.frombuffer(bytearray(proofs), dtype=torch.uint8).to("cuda"); dc = torch.frombuffer(bytearray(coms), dtype=torch.uint8).to("cuda")
 dv = torch.full((P,), 77, dtype=torch.uint8, device="cuda")
-ctx.set_verify_overlap(0)
+ctx.set_verify_overlap(int(os.environ.get("OV", "0")))
 for i in range(6):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ctx.rangeproof_verify_batch_device(gens, 64, 1, dp.data_ptr(), plen, dc.data_ptr(), P, dv.data_ptr()); ctx.sync()
