@@ -29,9 +29,9 @@ f = glob.glob('/tmp/tl/**/*kernel_trace.csv', recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # the last call = the last 10 kernels starting from a k_bpv_decompress
-idx = [i for i, r in enumerate(rows) if 'k_bpv_decompress' in r['Kernel_Name']][-1]
+idx = [i for i, r in enumerate(rows) if 'k_bpv_decompress' in r['Kernel_Name']][-2 if len(__import__('sys').argv) < 2 else -1]
 t0 = int(rows[idx]['Start_Timestamp'])
 for r in rows[idx:]:
     s, e = int(r['Start_Timestamp']) - t0, int(r['End_Timestamp']) - t0
-    print("%9.1f %9.1f %8.1f  %s" % (s / 1e3, e / 1e3, (e - s) / 1e3, r['Kernel_Name'][:60]))
+    print("%9.1f %9.1f %8.1f  q%-2s %s" % (s / 1e3, e / 1e3, (e - s) / 1e3, r.get('Queue_Id', '?'), r['Kernel_Name'][:60]))
 PY
