@@ -292,7 +292,8 @@ static VerifySizes verify_ws_sizes(const bp_ctx* ctx, const bp_gens* gens, int n
     if (allow_slice && (tp == -4 || (tp == 0 && nproofs * (size_t)slice_lpp <= 65536))) {
         tp = -slice_lpp;
     } else if (tp != 2 && tp != 4 && tp != 8 && tp != 16 && tp != 32 && tp != 64) {
-        tp = nproofs >= 65536 ? 2 : (nproofs >= 32768 ? 4 : (nproofs >= 12288 ? 8 : 16));
+        // (re-tuned with two calls in flight and the one-call-alone helper stream: profiles/r02_small_batch.txt E)
+        tp = nproofs >= 40960 ? 2 : (nproofs >= 14336 ? 4 : (nproofs >= 6144 ? 8 : 16));
         // aggregated proofs (n*m >= 512): the table part dominates and has no per-lane overhead, so take enough
         // lanes for two waves per SIMD (131072 lanes) even with few proofs in the batch
         if ((size_t)n_bits * m >= 512)
