@@ -420,10 +420,15 @@ size_t bpv_msm_vartab_bytes(int tp, size_t nproofs) {
     return blocks * 256 * bpv_ppl(tp) * (ECMUL_SLOTS * sizeof(xyzz) + ECMUL_NT * sizeof(affine_mem) + ECMUL_DIGB);
 }
 size_t bpv_msm_fixpart_bytes(size_t nproofs) { return 2 * nproofs * sizeof(xyzz); }  // fixed-generator sums | proof-specific sums (helper-stream form)
-// lanes per proof of the fixed-generator kernel: enough for 4 waves on every SIMD (262144 lanes) when the batch allows
+// lanes per proof of the fixed-generator kernel: enough for 4 waves on every SIMD (262144 lanes) when the batch allows, 64 lanes
+// only for batches of up to 2048 proofs (a 4096-proof batch spent more in the 64-lane tree than it won: 1.77 -> 1.54 ms per call in
+// flight at 32 lanes; profiles/r02_small_batch.txt F)
 static int bpv_fix_lanes(int tp, size_t nproofs, int nm) {
+    static const int forced = getenv("BP_FIX_LANES") ? atoi(getenv("BP_FIX_LANES")) : 0;  // tuning sweeps
+    if (forced == 2 || forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
     int tf = tp < 4 ? 4 : tp;
     while (tf < 64 && nproofs * (size_t)tf < 262144) tf *= 2;
+    if (tf == 64 && nproofs > 2048 && tp < 64) tf = 32;
     while (tf > 2 && tf > 2 * nm + 2) tf /= 2;
     return tf;
 }
