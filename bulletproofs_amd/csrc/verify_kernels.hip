@@ -428,7 +428,7 @@ static int bpv_fix_lanes(int tp, size_t nproofs, int nm) {
     if (forced == 2 || forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
     int tf = tp < 4 ? 4 : tp;
     while (tf < 64 && nproofs * (size_t)tf < 262144) tf *= 2;
-    if (tf == 64 && nproofs > 2048 && tp < 64) tf = 32;
+    if (tf == 64 && nproofs > 2048 && tp < 64 && nm <= 128) tf = 32;  // (aggregated proofs have thousands of terms per proof: the tree is nothing)
     while (tf > 2 && tf > 2 * nm + 2) tf /= 2;
     return tf;
 }
