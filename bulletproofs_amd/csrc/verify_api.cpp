@@ -294,10 +294,11 @@ static VerifySizes verify_ws_sizes(const bp_ctx* ctx, const bp_gens* gens, int n
     } else if (tp != 2 && tp != 4 && tp != 8 && tp != 16 && tp != 32 && tp != 64) {
         // (re-tuned with two calls in flight and the one-call-alone helper stream: profiles/r02_small_batch.txt E)
         tp = nproofs >= 40960 ? 2 : (nproofs >= 14336 ? 4 : (nproofs >= 6144 ? 8 : 16));
-        // aggregated proofs (n*m >= 512): the table part dominates and has no per-lane overhead, so take enough
-        // lanes for two waves per SIMD (131072 lanes) even with few proofs in the batch
+        // aggregated proofs (n*m >= 512): tens of proof-specific points per proof, so take enough lanes for one wave per SIMD
+        // (65536 lanes) even with few proofs in the batch; the table kernel picks its own lanes (bpv_fix_lanes).  4096 n=64 m=16
+        // proofs: 316 K proofs/s at 32 lanes (the earlier 131072-lane rule), 332 K at 16, 318 K at 8, 305 K at 4.
         if ((size_t)n_bits * m >= 512)
-            while (tp < 64 && nproofs * (size_t)tp < 131072) tp *= 2;
+            while (tp < 64 && nproofs * (size_t)tp < 65536) tp *= 2;
     }
     z.tp = tp;
     z.vartab = bpv_msm_vartab_bytes(tp, nproofs);
