@@ -194,7 +194,9 @@ void bp_verify_set_lanes(bp_ctx* ctx, int lanes);
  * context's stream.  The side stream does not wait for earlier work of the context: the proofs and commitments must be
  * complete in device memory when the call is made (they are for any caller that filled them on its own streams and
  * synchronised; the host-pointer entry points, which stage their inputs on the context's stream, never overlap).
- * on = 0: every kernel on the context's stream. */
+ * A call with nothing in flight beside it (a synchronous caller) still uses the side stream: its fixed-generator kernel runs
+ * there, beside its proof-specific kernel.
+ * on = 0: every kernel of every call on the context's stream, one after the other. */
 void bp_verify_set_overlap(bp_ctx* ctx, int on);
 
 /* bp_scalar_mul_batch — n independent out[i] = scalars[i] * points[i].
