@@ -487,31 +487,82 @@ BP_HD fq fq_mul_shift384(const fq& k, const uint32_t g[8]) {
     }
     return r;
 }
+// out[0 .. 4 + NB) = a[0..4) * b[0..NB): the 128-bit quotients times a lattice constant, plain integers
+template <int NB>
+BP_HD void fq_mul4(uint32_t* out, const uint32_t a[4], const uint32_t* b) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        c += (uint64_t)a[0] * b[j];
+        out[j] = (uint32_t)c;
+        c >>= 32;
+    }
+    out[NB] = (uint32_t)c;
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+        c = 0;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            c += (uint64_t)a[i] * b[j] + out[i + j];
+            out[i + j] = (uint32_t)c;
+            c >>= 32;
+        }
+        out[i + NB] = (uint32_t)c;
+    }
+}
 // k (plain, < q) -> magnitudes k1, k2 (< 2^129, plain) and their signs (true = negative).
+// With the rounded quotients c1 = round(b2 k / q), c2 = round(-b1 k / q) (< 2^128) the halves are small INTEGERS,
+//   k1 = k - c1 a1 - c2 a2,   k2 = -c1 b1 - c2 b2        (lattice basis (a1, b1), (a2, b2), a_i + b_i lambda = 0 mod q),
+// so four 128 x 128(129)-bit products and a few subtractions give them directly - 68 multiplies, where three Montgomery
+// multiplications mod q (k2 = c1 (-b1) + c2 (-b2), k1 = k - k2 lambda) took 400: k_glv_digits 80 -> 40 us per 2^20 scalars.
+// Same values as that form on every input (tests/test_host_arith.py::test_fq_glv_split against a Python model of both).
 BP_HD void fq_glv_split(const fq& k, fq& k1, bool& neg1, fq& k2, bool& neg2) {
     const uint32_t G1[8] = {0x45dbb031u, 0xe893209au, 0x71e8ca7fu, 0x3daa8a14u, 0x9284eb15u, 0xe86c90e4u, 0xa7d46bcdu, 0x3086d221u};
     const uint32_t G2[8] = {0x8ac47f71u, 0x1571b4aeu, 0x9df506c6u, 0x221208acu, 0x0abfe4c4u, 0x6f547fa9u, 0x010e8828u, 0xe4437ed6u};
-    const fq MB1_M = {{0x0ad9263cu, 0xc50468d0u, 0xfaa6ed42u, 0x1b1c8205u, 0x8ac47f71u, 0x1571b4aeu, 0x9df506c6u, 0x221208acu}};
-    const fq MB2_M = {{0x6a144696u, 0x0cac5e50u, 0xf3ba5939u, 0x1e8a8dc5u, 0xba244fceu, 0x176cdf65u, 0x8e173580u, 0xc25575ebu}};
-    const fq LAM_M = {{0xc9926c9eu, 0xf07deb3du, 0x83c6944cu, 0x2c93e7adu, 0x52697d91u, 0x73a96606u, 0x8558d639u, 0x53284017u}};
-    const uint32_t HALF_Q[8] = {0x681b20a0u, 0xdfe92f46u, 0x57a4501du, 0x5d576e73u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu};
-    fq c1 = fq_mul_shift384(k, G1), c2 = fq_mul_shift384(k, G2);
-    fq r2 = fq_add(fq_mont_mul(c1, MB1_M), fq_mont_mul(c2, MB2_M));  // mont_mul(a, b*R) = a*b
-    fq r1 = fq_sub(k, fq_mont_mul(r2, LAM_M));
-    // r > q/2  <=>  HALF_Q - r borrows
-    auto gt_half = [&](const fq& r) {
-        int64_t b = 0;
+    const uint32_t A1[4] = {0x9284eb15u, 0xe86c90e4u, 0xa7d46bcdu, 0x3086d221u};               // a1 = b2
+    const uint32_t MB1[4] = {0x0abfe4c3u, 0x6f547fa9u, 0x010e8828u, 0xe4437ed6u};              // -b1
+    const uint32_t A2[5] = {0x9d44cfd8u, 0x57c1108du, 0xa8e2f3f6u, 0x14ca50f7u, 0x00000001u};  // a2 (129 bits)
+    const fq c1 = fq_mul_shift384(k, G1), c2 = fq_mul_shift384(k, G2);
+    uint32_t t1[8], t2[9], u1[8], u2[8];
+    fq_mul4<4>(t1, c1.v, A1);
+    fq_mul4<5>(t2, c2.v, A2);
+    fq_mul4<4>(u1, c1.v, MB1);
+    fq_mul4<4>(u2, c2.v, A1);
+    // r1 = k - t1 - t2, r2 = u1 - u2 as 9-limb two's complement numbers (|r| < 2^129)
+    uint32_t r1[9], r2[9];
+    int64_t b = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            b += (int64_t)HALF_Q[i] - (int64_t)r.v[i];
-            b >>= 32;
-        }
-        return b != 0;
-    };
-    neg1 = gt_half(r1);
-    neg2 = gt_half(r2);
-    k1 = neg1 ? fq_neg(r1) : r1;
-    k2 = neg2 ? fq_neg(r2) : r2;
+    for (int i = 0; i < 9; i++) {
+        b += (int64_t)(i < 8 ? k.v[i] : 0u) - (int64_t)(i < 8 ? t1[i] : 0u) - (int64_t)t2[i];
+        r1[i] = (uint32_t)b;
+        b >>= 32;
+    }
+    b = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        b += (int64_t)(i < 8 ? u1[i] : 0u) - (int64_t)(i < 8 ? u2[i] : 0u);
+        r2[i] = (uint32_t)b;
+        b >>= 32;
+    }
+    neg1 = (r1[8] >> 31) != 0;
+    neg2 = (r2[8] >> 31) != 0;
+    // magnitudes: conditional two's-complement negation, low 8 limbs (the ninth is a sign extension)
+    uint64_t c = neg1 ? 1 : 0;
+    const uint32_t m1 = neg1 ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)(r1[i] ^ m1);
+        k1.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    c = neg2 ? 1 : 0;
+    const uint32_t m2 = neg2 ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)(r2[i] ^ m2);
+        k2.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
 }
 
 // 32 big-endian bytes -> scalar reduced mod q (`Scalar::from(&BigInt)` for 256-bit inputs).

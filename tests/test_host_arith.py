@@ -284,3 +284,29 @@ def test_sha256(L):
         o = ctypes.create_string_buffer(32)
         L.bpt_sha256(o, d, n)
         assert o.raw == hashlib.sha256(d).digest(), n
+
+
+def test_fq_glv_split(L):
+    """fq_glv_split (fq.h): k = k1 + k2 * lambda (mod q) with the rounded quotients of libsecp256k1's scalar_split_lambda;
+    magnitudes and signs against a Python model of the same formulas, on edge values and random scalars."""
+    G1 = 0x3086D221A7D46BCDE86C90E49284EB153DAA8A1471E8CA7FE893209A45DBB031
+    G2 = 0xE4437ED6010E88286F547FA90ABFE4C4221208AC9DF506C61571B4AE8AC47F71
+    A1 = 0x3086D221A7D46BCDE86C90E49284EB15          # = b2
+    MB1 = 0xE4437ED6010E88286F547FA90ABFE4C3         # = -b1
+    A2 = 0x114CA50F7A8E2F3F657C1108D9D44CFD8
+    LAM = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    assert (A1 + (-MB1) * LAM) % Q == 0 and (A2 + A1 * LAM) % Q == 0      # the lattice basis (a1, b1), (a2, b2)
+    rng = random.Random(11)
+    edge = [0, 1, 2, Q - 1, Q - 2, (Q - 1) // 2, (Q + 1) // 2, 2**128, 2**128 - 1, 2**255, 2**255 - 19, LAM, Q - LAM, LAM - 1, 2**192 + 12345]
+    for k in edge + [rng.randrange(Q) for _ in range(3000)] + [rng.randrange(2**130) for _ in range(200)]:
+        c1 = (k * G1 + 2**383) >> 384
+        c2 = (k * G2 + 2**383) >> 384
+        k2 = c1 * MB1 - c2 * A1          # -c1 b1 - c2 b2
+        k1 = k - c1 * A1 - c2 * A2
+        assert (k1 + k2 * LAM - k) % Q == 0 and abs(k1) < 2**129 and abs(k2) < 2**129
+        o1, o2 = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        signs = L.bpt_fq_glv(o1, o2, b32(k))
+        assert int.from_bytes(o1.raw, "big") == abs(k1) and int.from_bytes(o2.raw, "big") == abs(k2), hex(k)
+        # (a zero half may carry either sign)
+        assert (signs & 1) == (1 if k1 < 0 else 0) or k1 == 0
+        assert ((signs >> 1) & 1) == (1 if k2 < 0 else 0) or k2 == 0
