@@ -514,7 +514,8 @@ BP_HD void fq_mul4(uint32_t* out, const uint32_t a[4], const uint32_t* b) {
 // With the rounded quotients c1 = round(b2 k / q), c2 = round(-b1 k / q) (< 2^128) the halves are small INTEGERS,
 //   k1 = k - c1 a1 - c2 a2,   k2 = -c1 b1 - c2 b2        (lattice basis (a1, b1), (a2, b2), a_i + b_i lambda = 0 mod q),
 // so four 128 x 128(129)-bit products and a few subtractions give them directly - 68 multiplies, where three Montgomery
-// multiplications mod q (k2 = c1 (-b1) + c2 (-b2), k1 = k - k2 lambda) took 400: k_glv_digits 80 -> 40 us per 2^20 scalars.
+// multiplications mod q (k2 = c1 (-b1) + c2 (-b2), k1 = k - k2 lambda) took 400: k_glv_digits 168 -> 110 us on rocprofv3's average over
+// the MSM bench's calls (about 80 -> 52 us per 2^20 scalars).
 // Same values as that form on every input (tests/test_host_arith.py::test_fq_glv_split against a Python model of both).
 BP_HD void fq_glv_split(const fq& k, fq& k1, bool& neg1, fq& k2, bool& neg2) {
     const uint32_t G1[8] = {0x45dbb031u, 0xe893209au, 0x71e8ca7fu, 0x3daa8a14u, 0x9284eb15u, 0xe86c90e4u, 0xa7d46bcdu, 0x3086d221u};
