@@ -3,8 +3,9 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# last occurrence of k_glv_expand marks the start of the last call
-idx = max(i for i, r in enumerate(rows) if "k_glv_expand" in r["Kernel_Name"])
+# the last occurrences of k_glv_expand / k_glv_digits (they run side by side) mark the start of the last call
+idx = min(max(i for i, r in enumerate(rows) if "k_glv_expand" in r["Kernel_Name"]),
+          max(i for i, r in enumerate(rows) if "k_glv_digits" in r["Kernel_Name"]))
 t0 = int(rows[idx]["Start_Timestamp"])
 for r in rows[idx:]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
