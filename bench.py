@@ -44,7 +44,7 @@ MAD32_PER_POINT_MSM = 11833.0       # SURVEY.md 8(d), C5 model (2^20 points, c =
 # (fp_mul 102, fp_sqr 65 incl. the reduction, profiles/r02_fp_isa.txt):
 #   k_bpv_msm, n=64 m=1, 20-bit table, 2 lanes per proof: 23 900 fp_mul + 7 223 fp_sqr per proof
 #   whole bp_msm_device pipeline at 2^20 points:           157.0 fp_mul + 39.4 fp_sqr per point
-EXEC_MAD32_PER_PROOF_MSM = 2.907e6
+EXEC_MAD32_PER_PROOF_MSM = 2.907e6  # (2.920e6 in the final code's count on an 8192-proof call, which includes k_bpv_verdict's addition and a 32-lane tree)
 EXEC_MAD32_PER_PROOF_DECOMPRESS = 0.270e6  # k_bpv_decompress: 211 fp_mul + 3827 fp_sqr per proof (19 square roots), same file
 EXEC_MAD32_PER_POINT_MSM = 18578.0
 # HBM-side traffic of one verification MSM (the launch pair k_bpv_fix + k_bpv_msm) at the default configuration (65536
