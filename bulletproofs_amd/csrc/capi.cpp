@@ -120,16 +120,18 @@ SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
     pl.nchunks = (int)((n2 + ch - 1) / ch);
     if (pl.nchunks < 1) pl.nchunks = 1;
     pl.npad = (size_t)pl.nchunks * ch;
-    // segment length: ~4 segments per average bucket, at least 32 (lanes of a wave then do equal work
+    // segment length: ~2 segments per average bucket (the bucket reduction adds every segment's partial sum twice), at least 32 (lanes of a wave then do equal work
     // and k_srt_rowcol2 adds only a few partial sums per bucket)
     // Small MSMs are latency-bound: shorter segments (more lanes, shorter serial chains) while the grid
     // still has fewer than ~64k lanes.
     pl.L = 32;
-    while (pl.L < 256 && (size_t)pl.L * 8 <= n2 / (size_t)pl.NB) pl.L *= 2;
+    while (pl.L < 256 && (size_t)pl.L * 4 <= n2 / (size_t)pl.NB) pl.L *= 2;
     while (pl.L > 4 && (size_t)pl.W * n2 / pl.L < 65536) pl.L /= 2;
     if (const char* e = getenv("BP_MSM_L")) pl.L = atoi(e) > 0 ? atoi(e) : 32;
     pl.L = (pl.L + 7) & ~7;  // k_srt_acc reads the sorted entries in aligned 64-byte lines (8 entries)
     pl.nseg = (int)((pl.npad + pl.L - 1) / pl.L);
+    pl.Lmin = pl.L < 16 ? pl.L : 16;
+    pl.pstride = (int)((pl.npad + pl.Lmin - 1) / pl.Lmin);
     pl.lo_bits = c / 2;  // LO = 2^lo_bits, HI = NB / LO; LO + HI <= 256 for c <= 15
     if (pl.lo_bits > c - 1) pl.lo_bits = c - 1;
     return pl;
@@ -194,6 +196,8 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
     const size_t n2 = 2 * n;
     int path = ctx->msm_path;  // 0 auto, 1 LDS slices, 2 sorted
     if (const char* e = getenv("BP_MSM_PATH")) path = atoi(e);
+    const bool sort2 = path == 3;  // sorted path with the two-pass sort at any size
+    if (path == 3) path = 2;
     if (path == 0) path = n2 >= 256 ? 2 : 1;  // measured: the sorted path wins from 2^7 points up
     if (want_c) path = 2;
     const int forced_c = want_c ? want_c : ctx->forced_c;
@@ -216,22 +220,27 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
         HIPCHK(launch_msm_reduce_slices((const xyzz*)ctx->partial.p, pl.S, pl.W, (xyzz*)ctx->wsum.p, st), "reduce");
     } else {
         SortedPlan pl = plan_msm_sorted(n2, forced_c);
+        pl.sort2 = sort2 ? 1 : 0;
         *c_out = pl.c;
         *W_out = pl.W;
         const int W = pl.W;
         const size_t NB = pl.NB;
         const size_t nout = ((size_t)1 << pl.lo_bits) + (NB >> pl.lo_bits);
         if ((rc = ctx->digits.reserve((size_t)W * pl.npad * sizeof(int16_t))) != BP_OK) return rc;
-        if ((rc = ctx->srt[0].reserve((size_t)W * pl.nchunks * NB * 4)) != BP_OK) return rc;
+        size_t cnt_bytes = (size_t)W * pl.nchunks * NB * 4;
+        if (srt2_cnt_words(pl, n2) * 4 > cnt_bytes) cnt_bytes = srt2_cnt_words(pl, n2) * 4;
+        if ((rc = ctx->srt[0].reserve(cnt_bytes)) != BP_OK) return rc;
         if ((rc = ctx->srt[1].reserve((size_t)W * (NB + 1) * 4)) != BP_OK) return rc;
         if ((rc = ctx->srt[2].reserve((size_t)W * pl.npad * 8)) != BP_OK) return rc;
+        if ((rc = ctx->srt[3].reserve((size_t)W * pl.npad * 8)) != BP_OK) return rc;
         if ((rc = ctx->srt[4].reserve((size_t)W * NB * sizeof(xyzz))) != BP_OK) return rc;
-        if ((rc = ctx->srt[5].reserve((size_t)W * pl.nseg * sizeof(xyzz))) != BP_OK) return rc;
+        if ((rc = ctx->srt[5].reserve((size_t)W * pl.pstride * sizeof(xyzz))) != BP_OK) return rc;
         if ((rc = ctx->srt[6].reserve((size_t)W * nout * sizeof(xyzz))) != BP_OK) return rc;
         SortedBufs b;
         b.cnt = (uint32_t*)ctx->srt[0].p;
         b.bstart = (uint32_t*)ctx->srt[1].p;
         b.ent = (uint2*)ctx->srt[2].p;
+        b.tmp = (uint2*)ctx->srt[3].p;
         b.Bk = (xyzz*)ctx->srt[4].p;
         b.Pseg = (xyzz*)ctx->srt[5].p;
         b.RC = (xyzz*)ctx->srt[6].p;
@@ -246,7 +255,13 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
             memset(ss, 0, sizeof(*ss));
             ctx->srt_streams = ss;
             HIPCHK(ctx->side_stream(&ss->st2), "hipStreamCreate");  // the context's side stream (ctx.h)
-            HIPCHK(hipStreamCreateWithFlags(&ss->st3, hipStreamNonBlocking), "hipStreamCreate");
+            {   // the bucket reductions are the critical path beside the next group's accumulation: highest stream priority
+                int plo = 0, phi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+                int prio = phi;
+                if (const char* e = getenv("BP_MSM_PRIO")) prio = atoi(e) ? phi : 0;  // TUNING
+                HIPCHK(hipStreamCreateWithPriority(&ss->st3, hipStreamNonBlocking, prio), "hipStreamCreate");
+            }
             ss->st4 = ss->st2;  // a stream of its own shared st3's hardware queue (4 per process) and serialised the two
             for (int g = 0; g < SortedStreams::kMaxGroups; g++) {
                 HIPCHK(hipEventCreateWithFlags(&ss->ev_acc[g], hipEventDisableTiming), "hipEventCreate");
@@ -424,7 +439,7 @@ void bp_msm_set_window(bp_ctx* ctx, int c) {
     if (ctx) ctx->forced_c = c;
 }
 void bp_msm_set_path(bp_ctx* ctx, int path) {
-    if (ctx) ctx->msm_path = (path == 1 || path == 2) ? path : 0;
+    if (ctx) ctx->msm_path = (path >= 1 && path <= 3) ? path : 0;
 }
 void bp_msm_set_pipeline(bp_ctx* ctx, int mode) {
     if (ctx) ctx->msm_pipeline = mode == 1 ? 1 : 0;

@@ -33,14 +33,18 @@ hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine_mem* i
 // msm_sorted.hip: large-N path (global counting sort by bucket, balanced segment accumulation)
 struct SortedPlan {
     int c, W, NB, CH, nchunks, L, nseg, lo_bits;
+    int Lmin, pstride;  // shortest segment a window group may use (launch_msm_sorted) and the stride of Pseg it implies
     int ncu;  // compute units of the device (0 = unknown)
+    int sort2 = 0;  // 1 = two-pass sort at any size (bp_msm_set_path(ctx, 3): tests), 0 = from 2^15 virtual points
     size_t npad;
 };
 struct SortedBufs {
     uint32_t *cnt, *bstart;
     uint2* ent;
+    uint2* tmp;  // partition-sorted intermediate of the two-pass sort ([W][npad] like ent); nullptr = one-pass sort only
     xyzz *Bk, *Pseg, *RC;
 };
+size_t srt2_cnt_words(const SortedPlan& pl, size_t n2);  // 32-bit words of `cnt` the two-pass sort needs
 // side streams + events of the grouped pipeline (see launch_msm_sorted): st2 sorts, st3 bucket reductions, st4 Horner chain
 struct SortedStreams {
     static const int kMaxGroups = 8;

@@ -16,6 +16,7 @@
 
 #include "ec.h"
 #include "ecmul.h"
+#include "ecq.h"
 #include "fq.h"
 #include "kernels.h"
 
@@ -364,18 +365,20 @@ hipError_t launch_msm_tiny(const affine_mem* pts, const uint8_t* scalars_be, siz
     return hipGetLastError();
 }
 
-// result = init + sum_w 2^(c*w) wsum[w]  (Horner, one lane: the doubling chain is inherently serial),
-// normalised to the canonical affine element and written as 64 big-endian bytes.
+// result = init + sum_w 2^(c*w) wsum[w]  (Horner, one quad of lanes sharing every point operation, ecq.h: the doubling
+// chain is inherently serial), normalised to the canonical affine element and written as 64 big-endian bytes.
 __global__ __launch_bounds__(64) void k_msm_horner(const xyzz* __restrict__ wsum, int W, int c, const affine_mem* __restrict__ init, affine_mem* __restrict__ out_limbs,
                              uint8_t* __restrict__ out_be) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x >= 4 || blockIdx.x != 0) return;
     __builtin_amdgcn_s_setprio(3);
+    const int q = threadIdx.x;
     xyzz acc = wsum[W - 1];
     for (int w = W - 2; w >= 0; w--) {
-        acc = xyzz_dbl_n(acc, c);
+        acc = xyzzq_dbl_n(q, acc, c);
         xyzz o = wsum[w];
-        xyzz_add(acc, o);
+        xyzzq_add(q, acc, o);
     }
+    if (q != 0) return;
     if (init) xyzz_madd(acc, affine_load(*init));
     affine_mem m = affine_store(xyzz_to_affine_var(acc));
     if (out_limbs) *out_limbs = m;

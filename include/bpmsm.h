@@ -83,7 +83,8 @@ int bp_msm_combine(bp_ctx* ctx, const uint8_t* partials, size_t nparts, int c, c
 /* Testing / tuning knob: force the Pippenger window width (0 = automatic). */
 void bp_msm_set_window(bp_ctx* ctx, int c);
 /* Testing / tuning knob: 0 = automatic, 1 = LDS slice path (small / medium n), 2 = global sorted
- * path (large n).  Both compute the same sum; results are identical. */
+ * path (large n), 3 = sorted path with its two-pass bucket sort at any size (automatic from 2^14 terms).
+ * All compute the same sum; results are identical. */
 void bp_msm_set_path(bp_ctx* ctx, int path);
 /* Large MSMs (>= 2^16 terms) run their windows in groups, each group's latency-bound tail (bucket reduction, Horner
  * chain) on side streams beside the next group's accumulation: mode 0 (default), the lowest latency of ONE call.

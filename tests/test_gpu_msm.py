@@ -82,6 +82,27 @@ def test_msm_sorted_path_matches_oracle(ctx, oracle_c, c, n):
         ctx.set_path(0)
 
 
+@pytest.mark.parametrize("c,n", [(2, 5), (4, 40), (7, 300), (11, 1500), (12, 3000), (15, 3000), (0, 1), (0, 2600)])
+def test_msm_two_pass_sort_matches_oracle(ctx, oracle_c, c, n):
+    """The two-pass bucket sort of the sorted path (partition pass + in-LDS pass, msm_sorted.hip k_srt2_*; automatic from
+    2^14 terms) forced at sizes the oracle finishes: one partition / many, one bin per partition / 1024, empty partitions."""
+    rng = random.Random(5000 + 16 * c + n)
+    pts = _rand_points(rng, n, oracle_c)
+    ks = [rng.randrange(ec.Q) for _ in range(n)]
+    if n > 100:  # small and repeated scalars: empty windows, partitions larger than the LDS image
+        for i in range(0, n, 3):
+            ks[i] = rng.choice([1, 2, ec.Q - 1, 0x1234567, rng.randrange(1 << 30)])
+    init = oracle_c.mul(ec.G, 4711)
+    want = ec.enc64(oracle_c.msm_naive(pts, ks, init))
+    ctx.set_path(3)
+    ctx.set_window(c)
+    try:
+        assert ctx.msm(*_pack(pts, ks), ec.enc64(init)) == want
+    finally:
+        ctx.set_window(0)
+        ctx.set_path(0)
+
+
 def test_msm_sorted_path_skewed_buckets(ctx, oracle_c):
     """Bucket sizes far from uniform: the +-1 / 0 / small scalars of the prover's A commitment
     (range_proof.rs:93-107), repeated and opposite points, infinity, and buckets spanning many segments."""
@@ -94,7 +115,7 @@ def test_msm_sorted_path_skewed_buckets(ctx, oracle_c):
     ks = [rng.choice([0, 1, ec.Q - 1, 2, 3, 1 << 128, ec.Q - (1 << 128)]) for _ in range(n)]
     ks[9] = ks[8] = 5
     want = ec.enc64(oracle_c.msm_naive(pts, ks, None))
-    for path in (1, 2):
+    for path in (1, 2, 3):
         ctx.set_path(path)
         try:
             assert ctx.msm(*_pack(pts, ks), None) == want, path
