@@ -26,6 +26,10 @@ EXPORTED_SYMBOLS = [
     "bp_msm_partial_device",
     "bp_msm_partial",
     "bp_msm_combine",
+    "bp_msm_partial_device_out",
+    "bp_msm_combine_device",
+    "bp_ctx_record_event",
+    "bp_ctx_wait_event",
     "bp_gens_create",
     "bp_gens_destroy",
     "bp_gens_table_bytes",
@@ -159,6 +163,14 @@ def lib():
     L.bp_msm_partial.restype = i32
     L.bp_msm_combine.argtypes = [vp, cp, sz, i32, cp, cp]
     L.bp_msm_combine.restype = i32
+    L.bp_msm_partial_device_out.argtypes = [vp, vp, vp, sz, i32, vp]
+    L.bp_msm_partial_device_out.restype = i32
+    L.bp_msm_combine_device.argtypes = [vp, vp, sz, i32, cp, cp]
+    L.bp_msm_combine_device.restype = i32
+    L.bp_ctx_record_event.argtypes = [vp, vp]
+    L.bp_ctx_record_event.restype = i32
+    L.bp_ctx_wait_event.argtypes = [vp, vp]
+    L.bp_ctx_wait_event.restype = i32
     L.bp_msm_batch.argtypes = [vp, vp, vp, sz, cp]
     L.bp_msm_batch.restype = i32
     L.bp_generate_bases.argtypes = [i32, ctypes.c_uint64, sz, sz, cp, cp, cp, cp]
@@ -382,6 +394,24 @@ class Context:
         out = ctypes.create_string_buffer(lib().bp_msm_partial_bytes(c))
         _check(lib().bp_msm_partial_device(self._h, d_points, d_scalars, n, c, out))
         return out.raw
+
+    def msm_partial_device_out(self, d_points, d_scalars, n, c, d_partial_out):
+        """bp_msm_partial_device_out: the partial stays in device memory (d_partial_out: int device pointer); asynchronous."""
+        _check(lib().bp_msm_partial_device_out(self._h, ctypes.c_void_p(d_points), ctypes.c_void_p(d_scalars), n, c, ctypes.c_void_p(d_partial_out)))
+
+    def msm_combine_device(self, d_partials, nparts, c, init_xy=None):
+        """bp_msm_combine_device: partials of all ranks in device memory -> the 64-byte result."""
+        out = ctypes.create_string_buffer(64)
+        _check(lib().bp_msm_combine_device(self._h, ctypes.c_void_p(d_partials), nparts, c, init_xy, out))
+        return out.raw
+
+    def record_event(self, hip_event):
+        """Record the caller's hipEvent_t (int handle, e.g. torch.cuda.Event.cuda_event) on the context's stream."""
+        _check(lib().bp_ctx_record_event(self._h, ctypes.c_void_p(hip_event)))
+
+    def wait_event(self, hip_event):
+        """Order the context's later work (its stream and the verifier's side lane) after the caller's hipEvent_t."""
+        _check(lib().bp_ctx_wait_event(self._h, ctypes.c_void_p(hip_event)))
 
     def msm_partial(self, points_xy, scalars_be, c):
         n = len(scalars_be) // 32

@@ -53,32 +53,61 @@ def verify_batch_sharded(verify_fn, proofs, proof_len, coms, com_len, nproofs, d
     return gather_verdicts(local, nproofs, device)
 
 
-def msm_sharded(n, partial_fn, combine_fn, device=None):
-    """One large MSM across the ranks (SURVEY.md §8e mode (ii)): points are sharded N/G per rank,
-    every rank runs the bucket phase of the Pippenger pipeline on its shard (all windows) and produces
-    its per-window partial sums; the partials (W x 144 bytes per rank) are all-gathered - EC addition
-    is not a reduction operator, so gather + local combine, no all-reduce - and every rank adds the G
-    partials per window and runs ONE Horner combine.
-      partial_fn(lo, hi)      -> bytes     rank-local partial over terms [lo, hi)
-                                           (GPU: ctx.msm_partial_device(d_points, d_scalars, hi - lo, c))
-      combine_fn(parts, G)    -> 64 bytes  (GPU: ctx.msm_combine(parts, G, c))
-    Every rank must return partials of the same length (same window width c: take
-    c = bp_msm_auto_window(largest shard)).  Returns the same 64 bytes on every rank."""
+def msm_sharded_tensors(n, psize, partial_into, combine_from, device=None, after_partial=None, before_combine=None):
+    """One large MSM across the ranks (SURVEY.md 8e mode (ii)): points are sharded N/G per rank, every rank runs the
+    bucket phase of the Pippenger pipeline on its shard (all windows) into ITS per-window partial sums (psize =
+    bp_msm_partial_bytes(c) bytes, the same window width c on every rank: c = bp_msm_auto_window(largest shard)); the
+    partials are all-gathered - EC addition is not a reduction operator, so gather + local combine, no all-reduce - and
+    every rank adds the G partials per window and runs ONE Horner combine.  The buffers are torch uint8 tensors on
+    `device` and never leave it: on the GPU box they are device memory and the gather is RCCL over xGMI,
+        partial_into(lo, hi, t)   ctx.msm_partial_device_out(d_points, d_scalars, hi - lo, c, t.data_ptr())   (asynchronous)
+        after_partial()           ctx.record_event(ev) ; torch.cuda.current_stream().wait_event(ev)   - the collective is
+                                  queued right behind the bucket-reduction kernels, no host synchronisation
+        before_combine()          ev2.record() ; ctx.wait_event(ev2)
+        combine_from(t, G)        ctx.msm_combine_device(t.data_ptr(), G, c)   -> 64 bytes
+    in the CPU tests (gloo) they are host tensors filled / read by stand-ins.  Returns the same 64 bytes on every rank."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     lo, hi = shard_range(n, rank, world)
-    part = partial_fn(lo, hi)
+    mine = torch.empty(psize, dtype=torch.uint8, device=device)
+    partial_into(lo, hi, mine)
     if world == 1:
-        return combine_fn(part, 1)
-    buf = torch.frombuffer(bytearray(part), dtype=torch.uint8)
-    if device is not None:
-        buf = buf.to(device)
-    parts = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(parts, buf)
-    allp = b"".join(bytes(p.cpu().numpy().tobytes()) for p in parts)
-    return combine_fn(allp, world)
+        if after_partial:
+            after_partial()
+        if before_combine:
+            before_combine()
+        return combine_from(mine, 1)
+    allp = torch.empty(world * psize, dtype=torch.uint8, device=device)
+    if after_partial:
+        after_partial()
+    try:
+        dist.all_gather_into_tensor(allp, mine)
+    except (RuntimeError, NotImplementedError):  # a backend without the flat form
+        dist.all_gather(list(allp.view(world, psize).unbind(0)), mine)
+    if before_combine:
+        before_combine()
+    return combine_from(allp, world)
+
+
+def msm_sharded(n, partial_fn, combine_fn, device=None):
+    """The same exchange with byte strings at the boundary (host-pointer entry points bp_msm_partial / bp_msm_combine):
+      partial_fn(lo, hi)      -> bytes     rank-local partial over terms [lo, hi)
+      combine_fn(parts, G)    -> 64 bytes
+    A wrapper over msm_sharded_tensors - one code path for both forms."""
+    import torch
+
+    def combine_from(t, g):
+        return combine_fn(bytes(t.cpu().numpy().tobytes()), g)
+
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    lo, hi = shard_range(n, rank, world)
+    # the partial's size is only known once it exists: produce it first, then run the tensor form with a cached copy
+    part = partial_fn(lo, hi)
+    return msm_sharded_tensors(n, len(part), lambda lo_, hi_, t: t.copy_(torch.frombuffer(bytearray(part), dtype=torch.uint8)), combine_from, device)
 
 
 def largest_shard(n, world):

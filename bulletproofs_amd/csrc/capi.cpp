@@ -51,7 +51,7 @@ static int glv_windows(int c) { return (129 + c) / c; }
 MsmPlan plan_msm(size_t n2, int forced_c) {
     MsmPlan pl;
     int c;
-    if (const char* e = getenv("BP_MSM_C")) forced_c = atoi(e);  // tuning experiments
+    if (const char* e = bp_tune("BP_MSM_C")) forced_c = atoi(e);  // tuning experiments
     if (forced_c >= 2 && forced_c <= 12)
         c = forced_c;
     else if (n2 <= 32)
@@ -79,7 +79,7 @@ MsmPlan plan_msm(size_t n2, int forced_c) {
     if (M < 256) M = 256;
     if (M > 8192) M = 8192;
     while (M > (size_t)NB * 4 && M > 256 && ((n2 + M - 1) / M) * pl.W < 512) M /= 2;
-    if (const char* e = getenv("BP_MSM_M")) M = (size_t)atol(e);
+    if (const char* e = bp_tune("BP_MSM_M")) M = (size_t)atol(e);
     if (M > n2 && n2 > 0) M = n2;
     if (M == 0) M = 1;
     pl.M = (int)M;
@@ -95,7 +95,7 @@ MsmPlan plan_msm(size_t n2, int forced_c) {
 // latency-bound and want few windows.  c <= 15 (int16 digits, 64 KB LDS histograms).
 SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
     SortedPlan pl;
-    if (const char* e = getenv("BP_MSM_C")) forced_c = atoi(e);
+    if (const char* e = bp_tune("BP_MSM_C")) forced_c = atoi(e);
     int c = 0;
     if (forced_c >= 2 && forced_c <= 15) {
         c = forced_c;
@@ -115,7 +115,7 @@ SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
     // chunk of points per histogram workgroup: ~512 workgroups in flight, 4096..65536 points each
     size_t ch = 4096;
     while (ch < 65536 && ((n2 + ch - 1) / ch) * (size_t)pl.W > 512) ch *= 2;
-    if (const char* e = getenv("BP_MSM_CH")) ch = (size_t)atol(e) >= 1024 ? ((size_t)atol(e) + 7) & ~(size_t)7 : ch;  // read 8 digits at a time
+    if (const char* e = bp_tune("BP_MSM_CH")) ch = (size_t)atol(e) >= 1024 ? ((size_t)atol(e) + 7) & ~(size_t)7 : ch;  // read 8 digits at a time
     pl.CH = (int)ch;
     pl.nchunks = (int)((n2 + ch - 1) / ch);
     if (pl.nchunks < 1) pl.nchunks = 1;
@@ -127,7 +127,7 @@ SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
     pl.L = 32;
     while (pl.L < 256 && (size_t)pl.L * 4 <= n2 / (size_t)pl.NB) pl.L *= 2;
     while (pl.L > 4 && (size_t)pl.W * n2 / pl.L < 65536) pl.L /= 2;
-    if (const char* e = getenv("BP_MSM_L")) pl.L = atoi(e) > 0 ? atoi(e) : 32;
+    if (const char* e = bp_tune("BP_MSM_L")) pl.L = atoi(e) > 0 ? atoi(e) : 32;
     pl.L = (pl.L + 7) & ~7;  // k_srt_acc reads the sorted entries in aligned 64-byte lines (8 entries)
     pl.nseg = (int)((pl.npad + pl.L - 1) / pl.L);
     pl.Lmin = pl.L < 16 ? pl.L : 16;
@@ -144,7 +144,7 @@ SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
 // BP_MSM_GROUPS="3,3,2,1" overrides (tuning).
 static int plan_window_groups(int W, int* gsz) {
     int ng = 0;
-    if (const char* e = getenv("BP_MSM_GROUPS")) {
+    if (const char* e = bp_tune("BP_MSM_GROUPS")) {
         int left = W;
         const char* p = e;
         while (*p && left > 0 && ng < SortedStreams::kMaxGroups) {
@@ -195,7 +195,7 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
     }
     const size_t n2 = 2 * n;
     int path = ctx->msm_path;  // 0 auto, 1 LDS slices, 2 sorted
-    if (const char* e = getenv("BP_MSM_PATH")) path = atoi(e);
+    if (const char* e = bp_tune("BP_MSM_PATH")) path = atoi(e);
     const bool sort2 = path == 3;  // sorted path with the two-pass sort at any size
     if (path == 3) path = 2;
     if (path == 0) path = n2 >= 256 ? 2 : 1;  // measured: the sorted path wins from 2^7 points up
@@ -259,7 +259,7 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
                 int plo = 0, phi = 0;
                 (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
                 int prio = phi;
-                if (const char* e = getenv("BP_MSM_PRIO")) prio = atoi(e) ? phi : 0;  // TUNING
+                if (const char* e = bp_tune("BP_MSM_PRIO")) prio = atoi(e) ? phi : 0;  // TUNING
                 HIPCHK(hipStreamCreateWithPriority(&ss->st3, hipStreamNonBlocking, prio), "hipStreamCreate");
             }
             ss->st4 = ss->st2;  // a stream of its own shared st3's hardware queue (4 per process) and serialised the two
@@ -312,7 +312,7 @@ int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scal
         return BP_OK;
     }
     // tiny MSMs: four lanes per point in one workgroup (k_msm_tiny); forced paths / window widths keep the general pipeline
-    if (n <= msm_tiny_max() && ctx->msm_path == 0 && ctx->forced_c == 0 && !getenv("BP_MSM_PATH") && !getenv("BP_MSM_C")) {
+    if (n <= msm_tiny_max() && ctx->msm_path == 0 && ctx->forced_c == 0 && !bp_tune("BP_MSM_PATH") && !bp_tune("BP_MSM_C")) {
         if ((rc = ctx->partial.reserve(msm_tiny_scratch_bytes())) != BP_OK) return rc;
         HIPCHK(launch_msm_tiny(d_points, d_scalars_be, n, d_init, (xyzz*)ctx->partial.p, d_res, d_res_be, st), "msm tiny");
         return BP_OK;
@@ -466,6 +466,16 @@ int bp_msm_auto_window(size_t n) { return n ? plan_msm_sorted(2 * n, 0).c : 0; }
 
 size_t bp_msm_partial_bytes(int c) { return (c >= 2 && c <= 15) ? (size_t)glv_windows(c) * sizeof(xyzz) : 0; }
 
+// window sums of one shard into ctx->wsum (device), asynchronous on ctx->stream; n >= 1
+static int msm_partial_launch(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be, size_t n, int c) {
+    HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream), "memset err");
+    int rc;
+    if ((rc = ctx->points.reserve(n * sizeof(affine_mem))) != BP_OK) return rc;
+    HIPCHK(launch_ingest_points((const uint8_t*)d_points_xy, (affine_mem*)ctx->points.p, n, ctx->d_err, ctx->stream), "ingest");
+    int cu = 0, W = 0;
+    return msm_windows_on_device(ctx, (const affine_mem*)ctx->points.p, (const uint8_t*)d_scalars_be, n, c, &cu, &W);
+}
+
 int bp_msm_partial_device(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be, size_t n, int c, uint8_t* partial_out) {
     if (!ctx || !partial_out || c < 2 || c > 15 || (n && (!d_points_xy || !d_scalars_be))) return BP_EINVAL;
     CtxLock lk(ctx);
@@ -476,12 +486,8 @@ int bp_msm_partial_device(bp_ctx* ctx, const void* d_points_xy, const void* d_sc
         for (int w = 0; w < glv_windows(c); w++) memcpy(partial_out + (size_t)w * sizeof(xyzz), &inf, sizeof(xyzz));
         return BP_OK;
     }
-    HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream), "memset err");
     int rc;
-    if ((rc = ctx->points.reserve(n * sizeof(affine_mem))) != BP_OK) return rc;
-    HIPCHK(launch_ingest_points((const uint8_t*)d_points_xy, (affine_mem*)ctx->points.p, n, ctx->d_err, ctx->stream), "ingest");
-    int cu = 0, W = 0;
-    if ((rc = msm_windows_on_device(ctx, (const affine_mem*)ctx->points.p, (const uint8_t*)d_scalars_be, n, c, &cu, &W)) != BP_OK) return rc;
+    if ((rc = msm_partial_launch(ctx, d_points_xy, d_scalars_be, n, c)) != BP_OK) return rc;
     int h_err = 0;
     HIPCHK(hipMemcpyAsync(partial_out, ctx->wsum.p, bytes, hipMemcpyDeviceToHost, ctx->stream), "memcpy partial");
     HIPCHK(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), "memcpy err");
@@ -490,6 +496,26 @@ int bp_msm_partial_device(bp_ctx* ctx, const void* d_points_xy, const void* d_sc
         set_error_msg("input point not on curve");
         return BP_EPOINT;
     }
+    return BP_OK;
+}
+
+// The same with the partial LEFT IN DEVICE MEMORY and no synchronisation: the exchange step of a multi-GPU MSM launches
+// its all-gather right behind these kernels (bp_ctx_record_event bridges the context's stream to the collective's).
+// An off-curve input point is reported by the next bp_ctx_sync / bp_msm_combine_device of this context (BP_EPOINT).
+int bp_msm_partial_device_out(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be, size_t n, int c, void* d_partial_out) {
+    if (!ctx || !d_partial_out || c < 2 || c > 15 || (n && (!d_points_xy || !d_scalars_be))) return BP_EINVAL;
+    CtxLock lk(ctx);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t bytes = bp_msm_partial_bytes(c);
+    if (n == 0) {  // identity window sums: ZZ = 0 (all-zero bytes are an identity, ec.h)
+        HIPCHK(hipMemsetAsync(d_partial_out, 0, bytes, ctx->stream), "memset partial");
+        return BP_OK;
+    }
+    int rc;
+    if ((rc = msm_partial_launch(ctx, d_points_xy, d_scalars_be, n, c)) != BP_OK) return rc;
+    HIPCHK(hipMemcpyAsync(d_partial_out, ctx->wsum.p, bytes, hipMemcpyDeviceToDevice, ctx->stream), "memcpy partial");
+    HIPCHK(launch_or_flag(ctx->d_err + 1, ctx->d_err, ctx->stream), "park flag");
+    ctx->async_point_check = true;
     return BP_OK;
 }
 
@@ -510,7 +536,7 @@ int bp_msm_partial(bp_ctx* ctx, const uint8_t* points_xy, const uint8_t* scalars
     return bp_msm_partial_device(ctx, d_pts, d_sc, n, c, partial_out);
 }
 
-int bp_msm_combine(bp_ctx* ctx, const uint8_t* partials, size_t nparts, int c, const uint8_t* init_xy, uint8_t out_xy[64]) {
+static int msm_combine_impl(bp_ctx* ctx, const void* partials, bool on_device, size_t nparts, int c, const uint8_t* init_xy, uint8_t out_xy[64]) {
     if (!ctx || !out_xy || c < 2 || c > 15 || (nparts && !partials) || nparts > 4096) return BP_EINVAL;
     CtxLock lk(ctx);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
@@ -519,17 +545,46 @@ int bp_msm_combine(bp_ctx* ctx, const uint8_t* partials, size_t nparts, int c, c
     if ((rc = ctx->wsum.reserve(72 * sizeof(xyzz))) != BP_OK) return rc;
     if ((rc = ctx->result.reserve(sizeof(affine_mem) + 64)) != BP_OK) return rc;
     if ((rc = ctx->partial.reserve((nparts ? nparts : 1) * (size_t)W * sizeof(xyzz))) != BP_OK) return rc;
+    // an off-curve point of an earlier bp_msm_partial_device_out of this context (its flag was parked in d_err[1])
+    int h_async = 0;
+    if (ctx->async_point_check) HIPCHK(hipMemcpyAsync(&h_async, ctx->d_err + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), "memcpy err");
     HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream), "memset err");
     const affine_mem* d_init;
     if ((rc = upload_init(ctx, init_xy, &d_init)) != BP_OK) return rc;
-    if (nparts)
+    const xyzz* d_parts = (const xyzz*)partials;
+    if (nparts && !on_device) {
         HIPCHK(hipMemcpyAsync(ctx->partial.p, partials, nparts * (size_t)W * sizeof(xyzz), hipMemcpyHostToDevice, ctx->stream), "memcpy partials");
+        d_parts = (const xyzz*)ctx->partial.p;
+    }
     // partial[g][w] -> wsum[w]: the slice reduction kernel with "slices" strided by W
-    HIPCHK(launch_msm_reduce_parts((const xyzz*)ctx->partial.p, (int)nparts, W, (xyzz*)ctx->wsum.p, ctx->stream), "reduce parts");
+    HIPCHK(launch_msm_reduce_parts(d_parts, (int)nparts, W, (xyzz*)ctx->wsum.p, ctx->stream), "reduce parts");
     HIPCHK(launch_msm_horner((const xyzz*)ctx->wsum.p, W, c, d_init, (affine_mem*)ctx->result.p, (uint8_t*)ctx->result.p + sizeof(affine_mem),
                              ctx->stream),
            "horner");
-    return msm_fetch_result(ctx, out_xy);
+    rc = msm_fetch_result(ctx, out_xy);
+    if (ctx->async_point_check) {
+        ctx->async_point_check = false;
+        (void)hipMemsetAsync(ctx->d_err + 1, 0, sizeof(int), ctx->stream);
+        if (rc == BP_OK && h_async) {
+            set_error_msg("input point not on curve (bp_msm_partial_device_out)");
+            return BP_EPOINT;
+        }
+    }
+    return rc;
+}
+int bp_msm_combine(bp_ctx* ctx, const uint8_t* partials, size_t nparts, int c, const uint8_t* init_xy, uint8_t out_xy[64]) {
+    return msm_combine_impl(ctx, partials, false, nparts, c, init_xy, out_xy);
+}
+int bp_msm_combine_device(bp_ctx* ctx, const void* d_partials, size_t nparts, int c, const uint8_t* init_xy, uint8_t out_xy[64]) {
+    return msm_combine_impl(ctx, d_partials, true, nparts, c, init_xy, out_xy);
+}
+
+int bp_ctx_record_event(bp_ctx* ctx, void* hip_event) {
+    if (!ctx || !hip_event) return BP_EINVAL;
+    CtxLock lk(ctx);  // (orders the context's stream after the verifier's side lane first)
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    HIPCHK(hipEventRecord((hipEvent_t)hip_event, ctx->stream), "hipEventRecord");
+    return BP_OK;
 }
 
 int bp_msm(bp_ctx* ctx, const uint8_t* points_xy, const uint8_t* scalars_be, size_t n, const uint8_t* init_xy, uint8_t out_xy[64]) {

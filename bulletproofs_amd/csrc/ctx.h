@@ -36,7 +36,8 @@ struct bp_ctx {
     hipStream_t stream = nullptr;
     // large MSMs: window groups' bucket reduction (st3) and Horner chain (st2) overlap the next groups' accumulation
     bp::SortedStreams* srt_streams = nullptr;
-    int* d_err = nullptr;
+    int* d_err = nullptr;  // [0] input-validation flag of the current call, [1] parked flag of bp_msm_partial_device_out
+    bool async_point_check = false;  // d_err[1] is pending: bp_ctx_sync / bp_msm_combine_device report it
     int forced_c = 0;
     int ncu = 0;  // compute units of the device (window-group launches are sized per CU)
     int msm_path = 0;  // 0 auto, 1 LDS slice path, 2 sorted path (bp_msm_set_path)

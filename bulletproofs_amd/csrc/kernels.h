@@ -7,7 +7,17 @@
 #include "ec.h"
 #include "fq.h"
 
+#include <stdlib.h>
+
 namespace bp {
+
+// Tuning knobs (BP_MSM_*, BP_SRT2_HB, BP_FIX_LANES, BP_VERIFY_SMALL_SPLIT, BP_PROVE_CHUNK: experiment sweeps under scripts/)
+// are read from the environment only in -DBP_TUNING builds (make EXTRA=-DBP_TUNING); the product build never reads it.
+#ifdef BP_TUNING
+static inline const char* bp_tune(const char* name) { return getenv(name); }
+#else
+static inline const char* bp_tune(const char*) { return nullptr; }
+#endif
 
 // signed window digit of a fixed-base table term (tables go up to 20-bit windows: |digit| <= 2^19)
 typedef int32_t tdig_t;
@@ -27,6 +37,7 @@ size_t msm_tiny_max();
 size_t msm_tiny_scratch_bytes();
 hipError_t launch_msm_tiny(const affine_mem* pts, const uint8_t* scalars_be, size_t n, const affine_mem* init, xyzz* tabs, affine_mem* out_limbs,
                            uint8_t* out_be, hipStream_t st);
+hipError_t launch_or_flag(int* dst, const int* src, hipStream_t st);
 hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine_mem* init, affine_mem* out_limbs, uint8_t* out_be, hipStream_t st);
 
 

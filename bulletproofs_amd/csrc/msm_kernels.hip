@@ -392,6 +392,15 @@ __global__ __launch_bounds__(64) void k_msm_horner(const xyzz* __restrict__ wsum
     }
 }
 
+// dst |= src (one lane): parks a call's input-validation flag for a later, synchronising call to report
+__global__ void k_or_flag(int* __restrict__ dst, const int* __restrict__ src) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && *src) *dst = 1;
+}
+hipError_t launch_or_flag(int* dst, const int* src, hipStream_t st) {
+    hipLaunchKernelGGL(k_or_flag, dim3(1), dim3(64), 0, st, dst, src);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launch helpers
 size_t msm_slice_lds_bytes(int c, int M, int T) {

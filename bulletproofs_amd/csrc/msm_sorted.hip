@@ -171,7 +171,7 @@ static Srt2 srt2_params(const SortedPlan& pl, size_t n2) {
                                                        // multi-tile second pass of the larger half of the partitions costs (r3_c.log)
     if (bbits - hb > 10) hb = bbits - 10;
     if (hb > 13) hb = 13;
-    if (const char* e = getenv("BP_SRT2_HB")) hb = atoi(e) >= 0 && atoi(e) <= 13 && atoi(e) <= bbits && bbits - atoi(e) <= 10 ? atoi(e) : hb;  // TUNING
+    if (const char* e = bp_tune("BP_SRT2_HB")) hb = atoi(e) >= 0 && atoi(e) <= 13 && atoi(e) <= bbits && bbits - atoi(e) <= 10 ? atoi(e) : hb;  // TUNING
     s.lo2 = bbits - hb;
     s.NP = 1 << hb;
     size_t ch = (size_t)16 << hb;
@@ -798,7 +798,7 @@ static hipError_t srt_reduce_windows(const SortedPlan& pl, const SortedBufs& b, 
     // accumulation, where throughput counts: single lanes, one wave per output (quads there, 16 or 32 or 64 per output,
     // measured 2.22-2.33 ms per 2^20 MSM against 2.15: a quad spends four lanes on 2.2 times the speed; gpurun_out/r3_j.log).
     int T = lat ? 64 : 0;
-    if (const char* e = getenv("BP_MSM_RC_T")) {  // TUNING: "<latency T>,<throughput T>", 0 = single lanes (T = 64)
+    if (const char* e = bp_tune("BP_MSM_RC_T")) {  // TUNING: "<latency T>,<throughput T>", 0 = single lanes (T = 64)
         int a = atoi(e), b2 = a;
         if (const char* cpos = strchr(e, ',')) b2 = atoi(cpos + 1);
         T = lat ? a : b2;
@@ -841,7 +841,7 @@ hipError_t launch_msm_sorted(const affine_mem* pts, const affine_mem* lam, size_
     // at 2^20 (gpurun_out/r3_f.log).  L_g = group entries / resident lanes, a multiple of 8, at least pl.Lmin.
     size_t glanes[SortedStreams::kMaxGroups];
     for (int g = 0; g < SortedStreams::kMaxGroups; g++) glanes[g] = (size_t)(pl.ncu > 0 ? pl.ncu : 256) * (g == ng - 1 ? 256 : g == 0 ? 512 : 384);
-    if (const char* e2 = getenv("BP_MSM_LANES")) {  // TUNING: "a,b,c" lanes per group, the last value repeats
+    if (const char* e2 = bp_tune("BP_MSM_LANES")) {  // TUNING: "a,b,c" lanes per group, the last value repeats
         size_t v = 0;
         for (int g = 0; g < SortedStreams::kMaxGroups; g++) {
             if (*e2) {
@@ -857,7 +857,7 @@ hipError_t launch_msm_sorted(const affine_mem* pts, const affine_mem* lam, size_
     // accumulation - there the memory-bound sort runs beside the top group's latency-bound bucket reduction (st3), which
     // leaves most of the chip idle.  BP_MSM_SORTALL=1 (tuning): every window up front.
     bool sortall = true;
-    if (const char* e3 = getenv("BP_MSM_SORTALL")) sortall = atoi(e3) != 0;  // TUNING
+    if (const char* e3 = bp_tune("BP_MSM_SORTALL")) sortall = atoi(e3) != 0;  // TUNING
     if (sortall)
         srt_sort_windows(digits, n2, pl, b, 0, W, st);
     else

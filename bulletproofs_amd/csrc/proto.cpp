@@ -1694,7 +1694,7 @@ static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
     }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     size_t kChunk = 128;  // proofs (host threads) in flight
-    if (const char* e = getenv("BP_PROVE_CHUNK")) kChunk = (size_t)atol(e) >= 1 && (size_t)atol(e) <= 1024 ? (size_t)atol(e) : kChunk;
+    if (const char* e = bp_tune("BP_PROVE_CHUNK")) kChunk = (size_t)atol(e) >= 1 && (size_t)atol(e) <= 1024 ? (size_t)atol(e) : kChunk;
     int first_err = BP_OK;
     std::vector<int> st(nproofs, BP_OK);
     for (size_t base = 0; base < nproofs; base += kChunk) {

@@ -27,8 +27,9 @@ static int pick_table_window(int np) {
     // widest c in [4, 20] whose table (np * W * 2^(c-1) * 64 B) stays <= 64 GiB of the 288 GB HBM and whose build
     // (table + 2.25x as XYZZ scratch, freed afterwards) fits in 80 % of the memory that is free right now.
     // n=64 m=1: c = 20, 52.8 GiB, 13 gathers per generator term (c = 16: 4.3 GiB, 17 gathers); measured with a
-    // 68 GiB table (scratch/bigtable_test.py): the time per table addition is within 2 % of a 5 GiB table's -
-    // 64-byte gathers do not care how large the table is, so HBM capacity buys additions directly.
+    // 68 GiB table (scripts/experiments/bigtable_test.py, profiles/r02_bigtable_gather.txt): a table addition costs
+    // 10 % more than from a 5.5 GiB table (74.9 -> 82.1 ps) while the wider window removes 4 of 17 additions per
+    // generator term (-24 %), so HBM capacity still buys additions.
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
     int best = 4;
@@ -186,6 +187,17 @@ static void prof_mark(bp_ctx* ctx, int slot) {
     if (ctx->profiling) (void)hipEventRecord(ctx->prof_ev[slot], ctx->stream);
 }
 
+int bp_ctx_wait_event(bp_ctx* ctx, void* hip_event) {
+    if (!ctx || !hip_event) return BP_EINVAL;
+    CtxLock lk(ctx);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t side;
+    HIPCHK(ctx->side_stream(&side), "hipStreamCreate");
+    HIPCHK(hipStreamWaitEvent(ctx->stream, (hipEvent_t)hip_event, 0), "hipStreamWaitEvent");
+    HIPCHK(hipStreamWaitEvent(side, (hipEvent_t)hip_event, 0), "hipStreamWaitEvent");
+    return BP_OK;
+}
+
 int bp_ctx_sync(bp_ctx* ctx) {
     if (!ctx) return BP_EINVAL;
     CtxLock lk(ctx);
@@ -195,6 +207,16 @@ int bp_ctx_sync(bp_ctx* ctx) {
     ctx->v_calls = 0;  // the next call is one call alone again: on the context's stream, its table kernel on the side stream
     HIPCHK(hipStreamSynchronize(ctx->stream), "sync");
     if (ctx->profiling) prof_collect(ctx);
+    if (ctx->async_point_check) {  // an off-curve input point of bp_msm_partial_device_out
+        int h = 0;
+        HIPCHK(hipMemcpy(&h, ctx->d_err + 1, sizeof(int), hipMemcpyDeviceToHost), "memcpy err");
+        ctx->async_point_check = false;
+        (void)hipMemsetAsync(ctx->d_err + 1, 0, sizeof(int), ctx->stream);
+        if (h) {
+            set_error_msg("input point not on curve (bp_msm_partial_device_out)");
+            return BP_EPOINT;
+        }
+    }
     return BP_OK;
 }
 
@@ -440,6 +462,8 @@ static int verify_batch_launch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int
 static __device__ __align__(256) unsigned char scratch[BP_NOALLOC_SCRATCH_BYTES];
 static const int kMaxDevices = 64;
 static unsigned char* g_scratch_ptr[kMaxDevices];
+static hipEvent_t g_scratch_ev[kMaxDevices];   // recorded behind the last no-allocation call of the device: the next call's stream waits for it
+static bool g_scratch_busy[kMaxDevices];       // an event has been recorded
 static std::mutex g_scratch_mu;
 
 }  // extern "C"
@@ -451,8 +475,14 @@ int noalloc_init_device(int device) {  // the device must be current
     void* p = nullptr;
     hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
     if (e != hipSuccess || !p) {
-        set_error("hipGetSymbolAddress(scratch)", e);
-        return BP_EHIP;
+        // an optional feature must not take every other entry point down with it: the pointer stays null and only
+        // bp_rangeproof_verify_batch_device_noalloc reports BP_EHIP on this device
+        (void)hipGetLastError();
+        return BP_OK;
+    }
+    if (hipEventCreateWithFlags(&g_scratch_ev[device], hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return BP_OK;
     }
     g_scratch_ptr[device] = (unsigned char*)p;
     return BP_OK;
@@ -501,7 +531,14 @@ int bp_rangeproof_verify_batch_device_noalloc(bp_ctx* ctx, const bp_gens* gens, 
     ws.fixpart = (xyzz*)carve(z.fixpart);
     // The array keeps the previous call's contents.  Only `bad` must start at zero (verify_batch_launch clears it on the
     // stream); every other slice is written by the kernels of this call before it is read.
-    return verify_batch_launch(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, 0, ws, z.tp, ctx->stream);
+    // Calls of OTHER contexts / threads on this GPU use the same array: order this call's stream after the last one's
+    // kernels (one event per device, waited for and re-recorded under the device's mutex), so overlapping calls serialise.
+    std::lock_guard<std::mutex> glk(g_scratch_mu);
+    if (g_scratch_busy[ctx->device]) HIPCHK(hipStreamWaitEvent(ctx->stream, g_scratch_ev[ctx->device], 0), "hipStreamWaitEvent");
+    rc = verify_batch_launch(ctx, gens, n_bits, m, k, d_proofs, proof_len, d_coms_xy, nproofs, d_verdicts, 0, ws, z.tp, ctx->stream);
+    HIPCHK(hipEventRecord(g_scratch_ev[ctx->device], ctx->stream), "hipEventRecord");
+    g_scratch_busy[ctx->device] = true;
+    return rc;
 }
 
 int bp_wip_rangeproof_verify_batch_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
@@ -810,6 +847,10 @@ static int verify_batch_mixed(bp_ctx* ctx, const bp_gens* gens, int n_bits, cons
         }
         int k = 0;
         while (((size_t)1 << k) < nm) k++;
+        if (k > 16) {  // the same cap as check_batch_sizes: the constants kernels hold k + 2 prefix scalars per lane (BPV_MAXK)
+            set_error_msg("mixed batch: n_bits*m above 2^16 is not supported by the batch verifiers");
+            return BP_EINVAL;
+        }
         if (proof_off[i + 1] < proof_off[i] || proof_off[i + 1] - proof_off[i] != (size_t)(wip ? 195 : 292) + 66 * (size_t)k) {
             set_error_msg("mixed batch: proof length inconsistent with its m");
             return BP_EINVAL;

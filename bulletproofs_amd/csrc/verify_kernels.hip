@@ -424,7 +424,7 @@ size_t bpv_msm_fixpart_bytes(size_t nproofs) { return 2 * nproofs * sizeof(xyzz)
 // only for batches of up to 2048 proofs (a 4096-proof batch spent more in the 64-lane tree than it won: 1.77 -> 1.54 ms per call in
 // flight at 32 lanes; profiles/r02_small_batch.txt F)
 static int bpv_fix_lanes(int tp, size_t nproofs, int nm) {
-    static const int forced = getenv("BP_FIX_LANES") ? atoi(getenv("BP_FIX_LANES")) : 0;  // tuning sweeps
+    static const int forced = bp_tune("BP_FIX_LANES") ? atoi(bp_tune("BP_FIX_LANES")) : 0;  // tuning sweeps
     if (forced == 2 || forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
     int tf = tp < 4 ? 4 : tp;
     while (tf < 64 && nproofs * (size_t)tf < 262144) tf *= 2;
@@ -433,7 +433,7 @@ static int bpv_fix_lanes(int tp, size_t nproofs, int nm) {
     return tf;
 }
 int bpv_small_fused(int tp) {
-    static const bool split = getenv("BP_VERIFY_SMALL_SPLIT") != nullptr;  // A/B: the two-launch form
+    static const bool split = bp_tune("BP_VERIFY_SMALL_SPLIT") != nullptr;  // A/B: the two-launch form
     return (tp < 0 && -tp <= 128 && !split) ? -tp : 0;
 }
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,

@@ -79,6 +79,18 @@ size_t bp_msm_partial_bytes(int c);
 int bp_msm_partial_device(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be, size_t n, int c, uint8_t* partial_out);
 int bp_msm_partial(bp_ctx* ctx, const uint8_t* points_xy, const uint8_t* scalars_be, size_t n, int c, uint8_t* partial_out); /* host inputs */
 int bp_msm_combine(bp_ctx* ctx, const uint8_t* partials, size_t nparts, int c, const uint8_t* init_xy, uint8_t out_xy[64]);
+/* Device-resident exchange ("the gather launched on a stream right behind the bucket-reduce kernel"):
+ *   bp_msm_partial_device_out   leaves the partial in DEVICE memory (d_partial_out, bp_msm_partial_bytes(c) bytes) and does
+ *                               not synchronise; an off-curve input point is reported by the next bp_ctx_sync or
+ *                               bp_msm_combine_device of the context (BP_EPOINT);
+ *   bp_ctx_record_event         records the caller's hipEvent_t on the context's stream - the collective's stream waits for
+ *                               it (hipStreamWaitEvent / torch.cuda.Stream.wait_event) instead of the host;
+ *   all-gather of the partials on RCCL, device buffers, no host hop;
+ *   bp_ctx_wait_event           orders the context's stream after the event recorded behind the collective;
+ *   bp_msm_combine_device       bp_msm_combine over partials in DEVICE memory (nparts * bp_msm_partial_bytes(c) bytes). */
+int bp_msm_partial_device_out(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be, size_t n, int c, void* d_partial_out);
+int bp_msm_combine_device(bp_ctx* ctx, const void* d_partials, size_t nparts, int c, const uint8_t* init_xy, uint8_t out_xy[64]);
+int bp_ctx_record_event(bp_ctx* ctx, void* hip_event);
 
 /* Testing / tuning knob: force the Pippenger window width (0 = automatic). */
 void bp_msm_set_window(bp_ctx* ctx, int c);
@@ -159,13 +171,17 @@ int bp_wip_rangeproof_verify_batch_mixed(bp_ctx* ctx, const bp_gens* gens, int n
                                          const uint8_t* coms_xy, const uint32_t* m_per_proof, size_t nproofs, uint8_t* verdicts);
 
 /* bp_rangeproof_verify_batch_device_noalloc — bp_rangeproof_verify_batch_device for callers that cannot allocate.
- * No counterpart in the reference: it exists for callers that may not call hipMalloc (code under HIP graph capture,
- * tight serving loops, harnesses that forbid allocation).  Same arguments, same kernels, same verdict bytes; the
- * workspaces (decompressed points, digits, challenge scalars, lane-private window tables) live in a fixed device array
- * of bp_noalloc_scratch_bytes() = 64 MiB that every GPU the library runs on holds until the process ends, so the call
- * performs no hipMalloc / hipFree.  A batch whose workspaces exceed it (about 1800 n=64 m=1 proofs with the default
- * 20-bit table) returns BP_EINVAL and bp_last_error() says how many bytes it needs: split the batch.  All calls on one
- * GPU share that array: calls that overlap on the same GPU (two contexts, two threads) race — serialise them.
+ * No counterpart in the reference: it exists for callers that may not call hipMalloc (tight serving loops, harnesses that
+ * forbid allocation, code that runs while another thread captures a HIP graph).  Same arguments, same kernels, same
+ * verdict bytes; the workspaces (decompressed points, digits, challenge scalars, lane-private window tables) live in a
+ * fixed device array of bp_noalloc_scratch_bytes() = 64 MiB that every GPU the library runs on holds until the process
+ * ends, so the call performs no hipMalloc / hipFree.  It launches on the library's own stream (with hipSetDevice and an
+ * event wait), so it is NOT itself capturable into a caller's graph.  A batch whose workspaces exceed the array (about
+ * 1800 n=64 m=1 proofs with the default 20-bit table) returns BP_EINVAL and bp_last_error() says how many bytes it needs:
+ * split the batch.  All calls on one GPU share that array: calls that overlap on the same GPU (two contexts, two
+ * threads) are SERIALISED on the device - each call's stream waits for the event the previous call on that GPU recorded -
+ * so they do not race, and do not overlap either.  If the array's address could not be resolved on a device
+ * (hipGetSymbolAddress at bp_ctx_create) only this entry point fails there, with BP_EHIP.
  * Asynchronous on the context's stream until bp_ctx_sync, like the entry point it mirrors. */
 int bp_rangeproof_verify_batch_device_noalloc(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
                                               const void* d_coms_xy, size_t nproofs, void* d_verdicts);
@@ -188,17 +204,26 @@ int bp_rangeproof_verify_batch_rlc_device(bp_ctx* ctx, const bp_gens* gens, int 
 /* Tuning knob: lanes per proof in the verifier's MSM kernel (2, 4, 8, 16, 32 or 64; 0 = chosen by batch size; -4 = the
  * small-batch kernel with four lanes per proof-specific point, which 0 picks by itself when the batch is latency-bound). */
 void bp_verify_set_lanes(bp_ctx* ctx, int lanes);
-/* Overlap of successive bp_rangeproof_verify_batch_device / bp_wip_rangeproof_verify_batch_device calls (default on):
- * the scalar stage of a call (point decompression, Fiat-Shamir challenges, the 2nm+2 generator scalars; short,
- * latency-bound kernels) runs on a side stream into one of two workspace sets, beside the previous call's table and
- * ladder kernels, which fill the GPU on the context's stream; verdicts are still written in call order on the
- * context's stream.  The side stream does not wait for earlier work of the context: the proofs and commitments must be
- * complete in device memory when the call is made (they are for any caller that filled them on its own streams and
- * synchronised; the host-pointer entry points, which stage their inputs on the context's stream, never overlap).
- * A call with nothing in flight beside it (a synchronous caller) still uses the side stream: its fixed-generator kernel runs
- * there, beside its proof-specific kernel.
- * on = 0: every kernel of every call on the context's stream, one after the other. */
+/* Overlap of successive bp_rangeproof_verify_batch_device / bp_wip_rangeproof_verify_batch_device calls.
+ * DEFAULT ON since round 2 (an ABI-visible change of behaviour: round 1 ran every call on the context's stream).
+ * Contract while it is on:
+ *   - every SECOND asynchronous device call runs WHOLLY on a side lane - the context's side stream and a second set of
+ *     workspaces - including its verdict writes; it is NOT ordered against the calls before and after it on the context's
+ *     stream, so two batches are in flight and one fills the other's latency-bound stages;
+ *   - each call in flight therefore needs its OWN verdict buffer (reusing one buffer for successive un-synchronised calls
+ *     gives nondeterministic contents), and verdicts are complete only after bp_ctx_sync (or any other entry point of the
+ *     context, which first orders the context's stream after the side lane);
+ *   - the side lane does not wait for earlier work of the context's stream: the proofs and commitments must be complete in
+ *     device memory when the call is made, or the caller orders both lanes after its own producer stream with
+ *     bp_ctx_wait_event (the host-pointer entry points, which stage their inputs on the context's stream, never overlap);
+ *   - a call with nothing in flight beside it (a synchronous caller) still uses the side stream: its fixed-generator
+ *     kernel runs there, beside its proof-specific kernel.
+ * on = 0: every kernel of every call on the context's stream, one after the other (round 1's stream-ordered behaviour). */
 void bp_verify_set_overlap(bp_ctx* ctx, int on);
+/* Orders every LATER call of this context - its stream and the batch verifier's side lane - after `hip_event`, a
+ * hipEvent_t the caller recorded on the stream that produces the inputs (proofs, commitments, points, scalars) of the
+ * asynchronous device entry points.  No counterpart in the reference (host memory, one thread).  Does not block the host. */
+int bp_ctx_wait_event(bp_ctx* ctx, void* hip_event);
 
 /* bp_scalar_mul_batch — n independent out[i] = scalars[i] * points[i].
  * Replaces `hi_tag[i] = &h_vec[i] * &yi_inv[i]` (range_proof.rs:231-233, 327-329, 462-464). */

@@ -46,6 +46,9 @@ extern "C" {
     pub fn bp_last_error() -> *const c_char;
     pub fn bp_device_count() -> c_int;
     pub fn bp_ctx_sync(ctx: *mut bp_ctx) -> c_int;
+    /// `hip_event`: a `hipEvent_t` of the caller (stream bridging for the asynchronous device entry points)
+    pub fn bp_ctx_wait_event(ctx: *mut bp_ctx, hip_event: *mut c_void) -> c_int;
+    pub fn bp_ctx_record_event(ctx: *mut bp_ctx, hip_event: *mut c_void) -> c_int;
 
     // every `map(mul).fold(add)` site: range_proof.rs:116-122, 236-244, 770-774; inner_product.rs:73-115, 336-338;
     // range_proof_wip.rs:249-251, 370-372, 598-602; weighted_inner_product.rs:109-154, 500-504
@@ -58,6 +61,10 @@ extern "C" {
                                  partial_out: *mut u8) -> c_int;
     pub fn bp_msm_partial(ctx: *mut bp_ctx, points_xy: *const u8, scalars_be: *const u8, n: usize, c: c_int, partial_out: *mut u8) -> c_int;
     pub fn bp_msm_combine(ctx: *mut bp_ctx, partials: *const u8, nparts: usize, c: c_int, init_xy: *const u8, out_xy: *mut u8) -> c_int;
+    pub fn bp_msm_partial_device_out(ctx: *mut bp_ctx, d_points_xy: *const c_void, d_scalars_be: *const c_void, n: usize, c: c_int,
+                                     d_partial_out: *mut c_void) -> c_int;
+    pub fn bp_msm_combine_device(ctx: *mut bp_ctx, d_partials: *const c_void, nparts: usize, c: c_int, init_xy: *const u8,
+                                 out_xy: *mut u8) -> c_int;
     pub fn bp_msm_set_window(ctx: *mut bp_ctx, c: c_int);
     pub fn bp_msm_set_path(ctx: *mut bp_ctx, path: c_int);
     pub fn bp_msm_set_pipeline(ctx: *mut bp_ctx, mode: c_int);

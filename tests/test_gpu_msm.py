@@ -263,6 +263,66 @@ def test_msm_window_partials_combine(ctx, oracle_c, shards):
     assert ctx.msm_combine(parts, len(shards), c, ec.enc64(init)) == want
 
 
+@pytest.mark.parametrize("shards", [[700], [300, 0, 399, 1]])
+def test_msm_device_resident_exchange(ctx, oracle_c, shards):
+    """bp_msm_partial_device_out / bp_msm_combine_device with the partials in device memory (torch tensors stand in for the
+    all-gather's buffers) and the stream bridging of bulletproofs_amd.batch.msm_sharded_tensors (bp_ctx_record_event /
+    bp_ctx_wait_event on torch events): equal to the single MSM, bit for bit; the host-pointer pair reads the same bytes."""
+    import torch
+    import bulletproofs_amd as bpa
+    from bulletproofs_amd import batch
+    n = sum(shards)
+    rng = random.Random(900 + n)
+    pts = _rand_points(rng, n, oracle_c)
+    ks = [rng.randrange(2**256) for _ in range(n)]
+    init = oracle_c.mul(ec.G, 4242)
+    want = ec.enc64(oracle_c.msm_naive(pts, [k % ec.Q for k in ks], init))
+    c = bpa.msm_auto_window(max(shards))
+    psize = bpa.lib().bp_msm_partial_bytes(c)
+    pb, sb = _pack(pts, ks)
+    d_p = torch.frombuffer(bytearray(pb), dtype=torch.uint8).cuda()
+    d_s = torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda()
+    allp = torch.zeros(len(shards) * psize, dtype=torch.uint8, device="cuda")
+    ev = torch.cuda.Event()
+    ev.record()  # creates the handle
+    torch.cuda.synchronize()
+    lo = 0
+    for g, sz in enumerate(shards):
+        ctx.msm_partial_device_out(d_p.data_ptr() + 64 * lo, d_s.data_ptr() + 32 * lo, sz, c, allp.data_ptr() + g * psize)
+        lo += sz
+    ctx.record_event(ev.cuda_event)
+    torch.cuda.current_stream().wait_event(ev)
+    host_copy = bytes(allp.cpu().numpy().tobytes())  # on torch's stream, ordered behind the library's kernels by the event
+    ev2 = torch.cuda.Event()
+    ev2.record()
+    ctx.wait_event(ev2.cuda_event)
+    assert ctx.msm_combine_device(allp.data_ptr(), len(shards), c, ec.enc64(init)) == want
+    assert ctx.msm_combine(host_copy, len(shards), c, ec.enc64(init)) == want
+    # the batch layer's tensor form on one rank (no process group): the same entry points behind its hooks
+    got = batch.msm_sharded_tensors(
+        n, psize, lambda lo_, hi_, t: ctx.msm_partial_device_out(d_p.data_ptr() + 64 * lo_, d_s.data_ptr() + 32 * lo_, hi_ - lo_, c, t.data_ptr()),
+        lambda t, g: ctx.msm_combine_device(t.data_ptr(), g, c, ec.enc64(init)), torch.device("cuda"),
+        after_partial=lambda: (ctx.record_event(ev.cuda_event), torch.cuda.current_stream().wait_event(ev)),
+        before_combine=lambda: (ev2.record(), ctx.wait_event(ev2.cuda_event)))
+    assert got == want
+
+
+def test_msm_partial_device_out_reports_off_curve_point_at_sync(ctx):
+    import torch
+    import bulletproofs_amd as bpa
+    bad = (1).to_bytes(32, "big") + (1).to_bytes(32, "big")
+    d_p = torch.frombuffer(bytearray(bad * 300), dtype=torch.uint8).cuda()
+    d_s = torch.frombuffer(bytearray((3).to_bytes(32, "big") * 300), dtype=torch.uint8).cuda()
+    c = bpa.msm_auto_window(300)
+    out = torch.zeros(bpa.lib().bp_msm_partial_bytes(c), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.msm_partial_device_out(d_p.data_ptr(), d_s.data_ptr(), 300, c, out.data_ptr())
+    with pytest.raises(bpa.BpError) as e:
+        ctx.sync()
+    assert e.value.code == -2
+    ctx.sync()  # reported once
+
+
 def test_msm_partial_byte_format(ctx, oracle_c):
     """The partial buffers that cross the process boundary (bench.py --workload msm, tests/test_dist_gloo.py): tests/_partial.py
     reads real bp_msm_partial output (Horner-combined by the oracle == bp_msm) and bp_msm_combine reads partials written by

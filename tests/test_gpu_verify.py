@@ -374,6 +374,28 @@ def test_bp_mixed_aggregation_sizes_in_one_call(ctx):
         gens.close()
 
 
+def test_mixed_batch_rejects_more_than_2pow16_bits(ctx):
+    """the mixed entry points apply the k <= 16 cap of every other batch entry point (the constants kernels hold
+    k + 2 prefix scalars per lane).  Generators with n*m = 2^17 (a narrow 2-bit table: 4 GB) and one n=64 m=2048 'proof' of
+    the right length: BP_EINVAL, no launch."""
+    import hashlib
+    import bulletproofs_amd as bpa
+    nm = 1 << 17
+    pts = b""
+    for s0 in range(0, 2 * nm + 2, 1 << 16):
+        cnt = min(1 << 16, 2 * nm + 2 - s0)
+        pts += ctx.fixed_base_mul_batch(b"".join(hashlib.sha256(b"r3-gens-%d" % i).digest() for i in range(s0, s0 + cnt)))
+    gens = bpa.Gens(ctx, pts[:64 * nm], pts[64 * nm:128 * nm], pts[128 * nm:128 * nm + 64], pts[128 * nm + 64:], 2)
+    try:
+        for wip in (False, True):
+            plen = (195 if wip else 292) + 66 * 17
+            with pytest.raises(bpa.BpError) as e:
+                ctx.rangeproof_verify_batch_mixed(gens, 64, [bytes(plen)], [2048], bytes(64 * 2048), wip=wip)
+            assert e.value.code == -1
+    finally:
+        gens.close()
+
+
 def test_bpplus_mixed_aggregation_sizes_in_one_call(ctx, oracle_c):
     """bp_wip_rangeproof_verify_batch_mixed: Bulletproofs+ n=16 proofs with m = 1, 2, 4 (GPU-made, pinned by
     test_gpu_proto.py) + the golden n=16 m=2 case with its tampered variants, one call over the m=4 generators; verdicts ==

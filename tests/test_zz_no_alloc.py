@@ -62,3 +62,33 @@ def test_noalloc_matches_the_allocating_entry_point():
             assert set(d_v.cpu().tolist()) == {9}
         finally:
             gens.close()
+
+
+def test_noalloc_calls_of_two_contexts_serialise():
+    """Two contexts on one GPU share the fixed scratch array: their un-synchronised no-allocation calls are ordered on the
+    device by the per-GPU event (each call's stream waits for the previous call's kernels), so both give the allocating
+    entry point's verdicts instead of racing."""
+    import torch
+    dev = torch.device("cuda", 0)
+    with bpa.Context(0) as ctx_a, bpa.Context(0) as ctx_b:
+        b, plen, pb, cb = _batch(600, 4, mal_at=(7,))
+        gens = bpa.Gens(ctx_a, bytes.fromhex(b["g_vec"]), bytes.fromhex(b["h_vec"]), bytes.fromhex(b["G"]), bytes.fromhex(b["H"]), 12)
+        try:
+            halves = [(0, 350), (350, 600)]
+            d_p = [torch.frombuffer(bytearray(pb[lo * plen:hi * plen]), dtype=torch.uint8).to(dev) for lo, hi in halves]
+            d_c = [torch.frombuffer(bytearray(cb[lo * 64:hi * 64]), dtype=torch.uint8).to(dev) for lo, hi in halves]
+            want = [torch.full((hi - lo,), 77, dtype=torch.uint8, device=dev) for lo, hi in halves]
+            got = [torch.full((hi - lo,), 78, dtype=torch.uint8, device=dev) for lo, hi in halves]
+            torch.cuda.synchronize()
+            for i, (lo, hi) in enumerate(halves):
+                ctx_a.rangeproof_verify_batch_device(gens, 64, 1, d_p[i].data_ptr(), plen, d_c[i].data_ptr(), hi - lo, want[i].data_ptr())
+                ctx_a.sync()
+            for rep in range(3):  # back to back from two contexts, no synchronisation in between
+                for i, (c, (lo, hi)) in enumerate(zip((ctx_a, ctx_b), halves)):
+                    c.rangeproof_verify_batch_device_noalloc(gens, 64, 1, d_p[i].data_ptr(), plen, d_c[i].data_ptr(), hi - lo, got[i].data_ptr())
+            ctx_a.sync()
+            ctx_b.sync()
+            for i in range(2):
+                assert got[i].cpu().tolist() == want[i].cpu().tolist()
+        finally:
+            gens.close()
