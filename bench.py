@@ -39,22 +39,95 @@ MAD32_PER_PROOF_TOTAL = 6.60e6      # + the two fixed-base multiplications y*G, 
 # figure was 9.83e12; the measured one is the denominator used here).
 PEAK_MAD32_PER_S = 31.2e12
 MAD32_PER_POINT_MSM = 11833.0       # SURVEY.md 8(d), C5 model (2^20 points, c = 16)
-# Executed v_mad_u64_u32 lane-results per unit, COUNTED by the instrumented build (scripts/opcount.py ->
-# profiles/r02_opcount.json: every lane counts its fp_mul / fp_sqr calls) x the static v_mad_u64_u32 count of one call
-# (fp_mul 102, fp_sqr 65 incl. the reduction, profiles/r02_fp_isa.txt):
-#   k_bpv_msm, n=64 m=1, 20-bit table, 2 lanes per proof: 23 900 fp_mul + 7 223 fp_sqr per proof
-#   whole bp_msm_device pipeline at 2^20 points:           157.0 fp_mul + 39.4 fp_sqr per point
-EXEC_MAD32_PER_PROOF_MSM = 2.907e6  # (2.920e6 in the final code's count on an 8192-proof call, which includes k_bpv_verdict's addition and a 32-lane tree)
-EXEC_MAD32_PER_PROOF_DECOMPRESS = 0.270e6  # k_bpv_decompress: 211 fp_mul + 3827 fp_sqr per proof (19 square roots), same file
-EXEC_MAD32_PER_POINT_MSM = 18578.0
-# HBM-side traffic of one verification MSM (the launch pair k_bpv_fix + k_bpv_msm) at the default configuration (65536
-# distinct proofs, auto lanes, 20-bit table windows), from the separate --pmc passes in profiles/r02_pmc_read.csv /
-# r02_pmc_write.csv:  k_bpv_fix TCC_EA0_RDREQ 74.48e6 x 64 B (the 1690 table gathers per proof are 110.8e6 lines: a third
-# hit in L2) + 0.15e6 x 64 B written;  k_bpv_msm RDREQ 90.10e6 x 64 B + WRREQ 40.34e6 x 64 B + 17.85e6 x 32 B (the
-# lane-private window tables of the proof-specific points, built in and re-read from global scratch).  64-byte gathers, not
-# the 16-B/lane streaming pattern the guide's x2 correction was calibrated on: RDREQ x 64 B already matches the algorithmic
-# gather bytes, so no doubling.  13.7 GB in 12.9 ms = 1.06 TB/s, 13 % of the HBM peak: the kernels are VALU-bound.
-PMC_TRAFFIC_BYTES_DEFAULT = (74.48e6 + 90.10e6) * 64 + 0.15e6 * 64 + 40.34e6 * 64 + 17.85e6 * 32
+SURVEY_MAD32_PER_FIELD_OP = 64      # a field multiplication or squaring = 64 MAD32 (8x8 schoolbook)
+
+
+class Evidence:
+    """The executed-work counts and PMC traffic figures of the roofline block, READ from the committed evidence files of the
+    newest round that has them (profiles/rNN_opcount.json by scripts/opcount.py with the instrumented build; profiles/rNN_pmc_*.csv,
+    rNN_msm_pmc_*.csv by scripts/profiles.sh + profiles/summarize.py) - never retyped.  Two work units per figure:
+      executed      v_mad_u64_u32 lane-results: counted fp_mul x 102 + fp_sqr x 65 (the MADs of their ISA incl. the reduction)
+      survey unit   counted field operations x 64 MAD32 (SURVEY 8(d)'s definition of a field multiplication)"""
+
+    def __init__(self):
+        import csv
+        import glob
+        import re
+        self.files = {}
+        prof = os.path.join(ROOT, "profiles")
+
+        def newest(pattern, exclude=None):
+            c = [f for f in glob.glob(os.path.join(prof, pattern)) if not (exclude and exclude in os.path.basename(f))]
+            c.sort(key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)))
+            return c[-1] if c else None
+
+        def rows(f):
+            out = {}
+            if f:
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        out[(r["kernel"], r["counter"])] = float(r["avg_per_launch"])
+            return out
+
+        f = newest("r*_opcount.json")
+        self.files["opcount"] = os.path.basename(f) if f else None
+        self.oc = json.load(open(f)) if f else {}
+        for key, pat, excl in (("pmc_read", "r*_pmc_read.csv", "_msm_"), ("pmc_write", "r*_pmc_write.csv", "_msm_"),
+                               ("msm_pmc_read", "r*_msm_pmc_read.csv", None), ("msm_pmc_write", "r*_msm_pmc_write.csv", None)):
+            f = newest(pat, excl)
+            self.files[key] = os.path.basename(f) if f else None
+            setattr(self, key, rows(f))
+
+    def _verify_entry(self):
+        e = self.oc.get("k_bpv_msm_tableauto_lanes2")
+        return e if e and "executed_mad32_per_proof" in e else None
+
+    def verify_msm(self):
+        """(executed MAD32, survey-unit MAD32, counted at how many proofs) per n=64 m=1 proof of the launch pair k_bpv_fix + k_bpv_msm"""
+        e = self._verify_entry()
+        if not e:
+            return None, None, None
+        return (e["executed_mad32_per_proof"], (e["msm_only_fp_mul_per_proof"] + e["msm_only_fp_sqr_per_proof"]) * SURVEY_MAD32_PER_FIELD_OP,
+                e["proofs"])
+
+    def decompress(self):
+        e = self.oc.get("k_bpv_decompress")
+        if not e:
+            return None, None
+        return ((e["fp_mul"] * self.oc["mad_per_fp_mul"] + e["fp_sqr"] * self.oc["mad_per_fp_sqr"]) / e["proofs"],
+                (e["fp_mul"] + e["fp_sqr"]) * SURVEY_MAD32_PER_FIELD_OP / e["proofs"])
+
+    def msm_point(self, log2n=20):
+        e = self.oc.get("msm_2p%d" % log2n)
+        if not e:
+            return None, None
+        return e["executed_mad32_per_point"], (e["fp_mul"] + e["fp_sqr"]) * SURVEY_MAD32_PER_FIELD_OP / e["points"]
+
+    @staticmethod
+    def _bytes(rd, wr, kernel):
+        """HBM-side bytes per launch of the kernels whose name contains `kernel`: read requests x 64 B (32-byte ones x 32) +
+        write requests (64-byte ones x 64, the others x 32).  64-byte gathers, not the 16-B/lane streaming pattern the guide's
+        x2 correction was calibrated on: RDREQ x 64 B already matches the algorithmic gather bytes, so no doubling."""
+        tot, found = 0.0, False
+        for (k, c), v in rd.items():
+            if kernel in k and c == "TCC_EA0_RDREQ_sum":
+                tot += (v - rd.get((k, "TCC_EA0_RDREQ_32B_sum"), 0.0)) * 64 + rd.get((k, "TCC_EA0_RDREQ_32B_sum"), 0.0) * 32
+                found = True
+        for (k, c), v in wr.items():
+            if kernel in k and c == "TCC_EA0_WRREQ_sum":
+                w64 = wr.get((k, "TCC_EA0_WRREQ_64B_sum"), 0.0)
+                tot += w64 * 64 + (v - w64) * 32
+                found = True
+        return tot if found else None
+
+    def verify_traffic(self):
+        # the instantiations of the default configuration (65536 proofs per launch: 4 lanes per proof in the table kernel, 2 x 8 points in
+        # the ladder kernel); the batch sweep's smaller launches use others
+        a, b = self._bytes(self.pmc_read, self.pmc_write, "k_bpv_fix<4>"), self._bytes(self.pmc_read, self.pmc_write, "k_bpv_msm<2, 8>")
+        return (a + b) if (a is not None and b is not None) else None
+
+    def msm_acc_traffic(self):
+        return self._bytes(self.msm_pmc_read, self.msm_pmc_write, "k_srt_acc")
 
 
 # Rehearsal of the multi-rank path on a ONE-GPU box (BENCH_REHEARSAL=1 under torch.distributed.run): every rank uses
@@ -79,12 +152,6 @@ def dist_setup(world, local_rank):
 
 
 
-# HBM-side traffic of one k_srt_acc launch of the 2^20 raw MSM (three launches per MSM: 5 + 3 + 1 windows; average), from the
-# --pmc passes in profiles/r02_msm_pmc_read.csv / r02_msm_pmc_write.csv: TCC_EA0_RDREQ 12.09e6 x 64 B (64-byte point gathers +
-# the sorted entries, one line per 8 entries) + TCC_EA0_WRREQ 0.906e6 x 64 B + 0.139e6 x 32 B (bucket / segment partial sums).
-PMC_TRAFFIC_MSM_ACC_BYTES = 12.09e6 * 64 + 0.906e6 * 64 + 0.139e6 * 32
-
-
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,11 +164,14 @@ def parse():
                     help="verify = headline metric (default); msm = raw 2^20-point Pippenger MSM, points sharded over the ranks; "
                          "prove = single-proof prove / verify latencies of BASELINE.json configs[0], [1], [3] (one GPU)")
     ap.add_argument("--msm-log2", type=int, default=20)
+    ap.add_argument("--msm-per-gpu", action="store_true", help="--workload msm: weak scaling, 2^msm-log2 points on EVERY rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rlc-single", action="store_true", help="RLC side measurement with one context instead of two")
     ap.add_argument("--no-rlc", action="store_true", help="skip the random-linear-combination side measurement")
     ap.add_argument("--no-bpplus", action="store_true", help="skip the Bulletproofs+ batch side measurement")
     ap.add_argument("--no-c2", action="store_true", help="skip the n=64 m=16 batch side measurement")
+    ap.add_argument("--no-c4", action="store_true", help="skip the Bulletproofs+ n=64 m=64 batch side measurement (configs[3])")
+    ap.add_argument("--no-prove", action="store_true", help="skip the prover side measurements (configs[0], [1], [3])")
     ap.add_argument("--no-msm", action="store_true", help="skip the raw 2^k-point MSM side measurement")
     ap.add_argument("--no-overlap", action="store_true", help="bp_verify_set_overlap(ctx, 0): successive device calls one after the other (A/B)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep")
@@ -196,6 +266,7 @@ def cpu_baseline(batch, sample):
     out = {"value": done / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
            "sample": "%d n=64 m=1 proofs, oracle aggregated_verify (term-by-term MSM in C, as range_proof.rs:772-774)" % done}
     ncores = min(16, os.cpu_count() or 1)  # the GPU box's share is 16 cores whatever os.cpu_count() says
+    procs = []
     try:
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "8"], stdout=subprocess.PIPE, text=True)
                  for _ in range(ncores)]
@@ -209,6 +280,15 @@ def cpu_baseline(batch, sample):
                             "sample": "%d proofs over %d processes of the same loop, %.1f s" % (tot, ncores, tmax)}
     except Exception as e:  # a baseline, never a reason to lose the bench line
         out["all_cores"] = {"error": repr(e)[:200]}
+    finally:  # no worker outlives this function (a timed-out communicate() leaves the others running)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                pass
     rate = _openssl_mul_rate()
     if rate:
         out["openssl_ec_point_mul"] = {"mul_per_s": rate, "proofs_per_s_equiv": rate / 147.0, "cores": 1,
@@ -217,10 +297,33 @@ def cpu_baseline(batch, sample):
     return out
 
 
+def msm_roofline(ev, mpts_per_gpu, log2n):
+    """roofline object of the raw MSM: whole bp_msm_device pipeline against the measured MAD peak, in three work units."""
+    ex, su = ev.msm_point(log2n)
+    rate = mpts_per_gpu * 1e6
+    return {"bound": "valu_int32_mad", "kernel": "whole bp_msm_device pipeline (dominant kernel k_srt_acc)",
+            "achieved": rate * (ex or MAD32_PER_POINT_MSM) / 1e12, "peak": PEAK_MAD32_PER_S / 1e12, "unit": "TMAD32/s",
+            "frac": rate * (ex or MAD32_PER_POINT_MSM) / PEAK_MAD32_PER_S,
+            "frac_executed": rate * ex / PEAK_MAD32_PER_S if ex else None,
+            "frac_survey_unit": rate * su / PEAK_MAD32_PER_S if su else None,
+            "frac_model": rate * MAD32_PER_POINT_MSM / PEAK_MAD32_PER_S,
+            "executed_mad32_per_point": ex, "survey_unit_mad32_per_point": su, "model_mad32_per_point": MAD32_PER_POINT_MSM,
+            "what": "frac = frac_executed (counted fp_mul x 102 + fp_sqr x 65 per point, %s) when a count exists for this size, else "
+                    "frac_model; frac_survey_unit = counted field operations x 64 MAD32 (SURVEY 8(d)'s unit); frac_model = SURVEY 8(d)'s "
+                    "Pippenger model (c = 16)" % ev.files.get("opcount"),
+            "traffic": ev.msm_acc_traffic() if log2n == 20 else None,
+            "traffic_unit": "bytes per k_srt_acc launch (PMC, %s / %s); algorithmic per MSM: 18.9 M entries x (8 B entry + 64 B point) "
+                            "= 1.36 GB over the launches of one MSM" % (ev.files.get("msm_pmc_read"), ev.files.get("msm_pmc_write")),
+            "evidence_files": ev.files}
+
+
 def bench_msm(args):
-    """BASELINE.json configs[4]: raw Pippenger MSM of 2^k secp256k1 points; points sharded N/G per rank,
-    per-rank per-window partial sums all-gathered over RCCL, added, one Horner combine (bulletproofs_amd/batch.py: msm_sharded).
-    Strong scaling (total work fixed).  Inputs resident in HBM; the 64-byte result returns to the host."""
+    """BASELINE.json configs[4]: raw Pippenger MSM of 2^k secp256k1 points; points sharded N/G per rank, per-rank per-window
+    partial sums all-gathered over RCCL in DEVICE memory right behind the bucket-reduction kernels (no host hop:
+    bp_msm_partial_device_out -> bp_ctx_record_event -> all_gather_into_tensor -> bp_ctx_wait_event -> bp_msm_combine_device;
+    bulletproofs_amd/batch.py: msm_sharded_tensors), added, one Horner combine.  Inputs resident in HBM; the 64-byte result
+    returns to the host.  Default: STRONG scaling (2^--msm-log2 points in total).  --msm-per-gpu: WEAK scaling (2^--msm-log2
+    points on every rank, N * 2^k in total, the same exchange)."""
     import hashlib
     import torch
     import torch.distributed as dist
@@ -230,7 +333,7 @@ def bench_msm(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     local_rank, dev, cdev = dist_setup(world, local_rank)
-    N = 1 << args.msm_log2
+    N = (1 << args.msm_log2) * (world if args.msm_per_gpu else 1)
     lo, hi = bt.shard_range(N, rank, world)
     n = hi - lo
     ctx = bpa.Context(local_rank)
@@ -251,12 +354,38 @@ def bench_msm(args):
     torch.cuda.synchronize()
 
     cwin = bpa.msm_auto_window(bt.largest_shard(N, world))
+    psize = bpa.lib().bp_msm_partial_bytes(cwin)
+    ev_a, ev_b = torch.cuda.Event(), torch.cuda.Event()
+    ev_a.record()
+    ev_b.record()  # (creates the handles)
+    torch.cuda.synchronize()
+    on_gpu = cdev.type == "cuda"  # the one-GPU rehearsal moves host tensors over gloo
+
+    def partial_into(lo_, hi_, t):
+        if on_gpu:
+            ctx.msm_partial_device_out(d_pts.data_ptr(), d_sc.data_ptr(), hi_ - lo_, cwin, t.data_ptr())
+        else:
+            t.copy_(torch.frombuffer(bytearray(ctx.msm_partial_device(d_pts.data_ptr(), d_sc.data_ptr(), hi_ - lo_, cwin)), dtype=torch.uint8))
+
+    def after_partial():  # the collective's stream waits for the library's kernels, the host does not
+        if on_gpu:
+            ctx.record_event(ev_a.cuda_event)
+            torch.cuda.current_stream().wait_event(ev_a)
+
+    def before_combine():
+        if on_gpu:
+            ev_b.record()
+            ctx.wait_event(ev_b.cuda_event)
+
+    def combine_from(t, g):
+        if on_gpu:
+            return ctx.msm_combine_device(t.data_ptr(), g, cwin)
+        return ctx.msm_combine(bytes(t.numpy().tobytes()), g, cwin)
 
     def step():
         if world == 1:
             return ctx.msm_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
-        return bt.msm_sharded(N, lambda lo_, hi_: ctx.msm_partial_device(d_pts.data_ptr(), d_sc.data_ptr(), hi_ - lo_, cwin),
-                              lambda parts, g: ctx.msm_combine(parts, g, cwin), cdev)
+        return bt.msm_sharded_tensors(N, psize, partial_into, combine_from, cdev, after_partial, before_combine)
 
     for _ in range(args.warmup):
         res = step()
@@ -304,20 +433,18 @@ def bench_msm(args):
         ctx_b.close()
     if rank == 0:
         mpts = N * args.steps / dt / 1e6
-        mad_per_point = MAD32_PER_POINT_MSM
+        ev = Evidence()
+        shard_log2 = (bt.largest_shard(N, world) - 1).bit_length()
         print(json.dumps({
             "metric": "MSM Mpts/s (raw Pippenger MSM, secp256k1)", "value": mpts, "unit": "Mpts/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "u32 (256-bit modular integer arithmetic)",
+            "scaling": "weak" if args.msm_per_gpu else "strong", "vs_baseline": None, "dtype": "u32 (256-bit modular integer arithmetic)",
             "data": "synthetic (P_i = r_i*G, SHA-256 counter-stream scalars)",
-            "config": {"workload": "raw MSM of 2^%d points, points sharded over %d GPU(s), partial sums all-gathered" % (args.msm_log2, world),
-                       "result": res.hex()},
+            "config": {"workload": "raw MSM of %d points (%s), points sharded over %d GPU(s), per-window partial sums all-gathered in device "
+                                   "memory" % (N, "2^%d per GPU" % args.msm_log2 if args.msm_per_gpu else "2^%d in total" % args.msm_log2, world),
+                       "points_per_gpu": n, "window_bits": cwin, "exchange_bytes_per_rank": psize, "result": res.hex()},
             "two_in_flight": two,
-            "roofline": {"bound": "valu_int32_mad", "kernel": "whole bp_msm_device pipeline (dominant kernel k_srt_acc)", "achieved": mpts * 1e6 * mad_per_point / world / 1e12,
-                         "peak": PEAK_MAD32_PER_S / 1e12, "unit": "TMAD32/s", "frac": mpts * 1e6 * mad_per_point / world / PEAK_MAD32_PER_S,
-                         "traffic": PMC_TRAFFIC_MSM_ACC_BYTES if (args.msm_log2 == 20 and world == 1) else None,
-                         "traffic_unit": "bytes per k_srt_acc launch, three launches per MSM (PMC, profiles/r02_msm_pmc_*.csv); algorithmic per MSM: "
-                                         "9.4 M entries x (8 B entry + 64 B point) = 0.68 GB"}}), flush=True)
+            "roofline": msm_roofline(ev, mpts / world, shard_log2)}), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
@@ -604,13 +731,7 @@ def msm_side(ctx, dev, log2n, steps):
             c.close()
     return {"value": mpts, "unit": "Mpts/s", "log2_points": log2n, "ms_per_msm": dt * 1e3, "result": res.hex(), "contexts_in_flight": two,
             "what": "bp_msm_device, one call at a time, inputs resident in HBM, 64-byte result returned to the host",
-            "roofline": {"bound": "valu_int32_mad", "kernel": "whole bp_msm_device pipeline (dominant kernel k_srt_acc)",
-                         "achieved": mpts * 1e6 * MAD32_PER_POINT_MSM / 1e12, "peak": PEAK_MAD32_PER_S / 1e12, "unit": "TMAD32/s",
-                         "frac": mpts * 1e6 * (EXEC_MAD32_PER_POINT_MSM if log2n == 20 else MAD32_PER_POINT_MSM) / PEAK_MAD32_PER_S,
-                         "frac_model": mpts * 1e6 * MAD32_PER_POINT_MSM / PEAK_MAD32_PER_S,
-                         "frac_executed": (mpts * 1e6 * EXEC_MAD32_PER_POINT_MSM / PEAK_MAD32_PER_S) if log2n == 20 else None,
-                         "executed_mad32_per_point": EXEC_MAD32_PER_POINT_MSM if log2n == 20 else None, "model_mad32_per_point": MAD32_PER_POINT_MSM,
-                         "traffic": None}}
+            "roofline": msm_roofline(Evidence(), mpts, log2n)}
 
 
 def main():
@@ -647,13 +768,32 @@ def main():
         ctx.set_verify_lanes(args.lanes)
     TX_AT = 4 * 33 + 64 + 31  # last byte of tx
 
+    # The proof batch is made ONCE per node - rank 0's GPU batch prover - and broadcast: the batch prover's per-proof scalar
+    # work runs on host threads, and eight ranks generating at once fight for the same cores before the first timed step
+    # (10.8 s alone, 12.5 s with two ranks in round 2's rehearsal).  Every rank then verifies the same 65536 distinct proofs.
     t_gen = time.perf_counter()
-    proofs, coms, plen = make_distinct_batch(ctx, gens, G_xy, H_xy, 0, 1, P, b"bpmsm-bench-c3-rank%d" % rank)
+    plen = 292 + 66 * 6
+    if rank == 0:
+        proofs, coms, plen = make_distinct_batch(ctx, gens, G_xy, H_xy, 0, 1, P, b"bpmsm-bench-c3")
+        pb = bytearray(proofs)
+        want = tamper_batch(pb, plen, P, TX_AT)
+        d_proofs = torch.frombuffer(pb, dtype=torch.uint8).to(dev)
+        d_coms = torch.frombuffer(bytearray(coms), dtype=torch.uint8).to(dev)
+    else:
+        proofs = None
+        want = tamper_batch(bytearray(P * plen), plen, P, TX_AT)
+        d_proofs = torch.empty(P * plen, dtype=torch.uint8, device=dev)
+        d_coms = torch.empty(P * 64, dtype=torch.uint8, device=dev)
+    if world > 1:
+        if REHEARSAL:  # gloo: host tensors
+            hp, hc = d_proofs.cpu(), d_coms.cpu()
+            dist.broadcast(hp, 0)
+            dist.broadcast(hc, 0)
+            d_proofs, d_coms = hp.to(dev), hc.to(dev)
+        else:
+            dist.broadcast(d_proofs, 0)
+            dist.broadcast(d_coms, 0)
     t_gen = time.perf_counter() - t_gen
-    pb = bytearray(proofs)
-    want = tamper_batch(pb, plen, P, TX_AT)
-    d_proofs = torch.frombuffer(pb, dtype=torch.uint8).to(dev)
-    d_coms = torch.frombuffer(bytearray(coms), dtype=torch.uint8).to(dev)
     # Successive device calls of one context overlap (bp_verify_set_overlap: two batches in flight), so every call in
     # flight gets a verdict buffer of its own.
     d_verd = [torch.full((P,), 77, dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -778,7 +918,9 @@ def main():
     # value, never as it: `value` is N independent aggregated_verify checks, the reference's semantics).
     rlc = None
     if not args.no_rlc:
-        d_valid = torch.frombuffer(bytearray(proofs), dtype=torch.uint8).to(dev)
+        d_valid = d_proofs.clone()  # the all-valid version: flip the tampered bits back
+        idx = torch.arange(5, P, 16, device=dev, dtype=torch.int64) * plen + TX_AT
+        d_valid[idx] ^= 1
         d_v2 = torch.full((P,), 77, dtype=torch.uint8, device=dev)
         seed = bytes((7 * i + rank) & 255 for i in range(32))
         fb = ctx.rangeproof_verify_batch_rlc_device(gens, 64, 1, d_valid.data_ptr(), plen, d_coms.data_ptr(), P, seed, d_v2.data_ptr())
@@ -820,7 +962,47 @@ def main():
     # provers (pinned to the oracle's bytes by tests/test_gpu_proto.py), 1/16 tampered, verdicts checked:
     #   bpplus_batch  RangeProofWIP::aggregated_verify (Bulletproofs+), n=64 m=1, as many proofs per step as the headline
     #   c2_batch      RangeProof::aggregated_verify at BASELINE.json configs[1]'s shape, n=64 m=16 (2089-term MSM per proof)
-    def side_batch(kind, m, P_side, what):
+    def be32(xs):
+        return b"".join(int(x, 16).to_bytes(32, "big") for x in xs)
+
+    def prover_numbers(gens_x, kind, fixture, nb):
+        """Single-proof prove / aggregated_verify latency and batch-prove rate on a golden fixture (tests/golden), the proof
+        bytes compared with the fixture's (RangeProof::prove range_proof.rs:45-263 / RangeProofWIP::prove range_proof_wip.rs:101-274)."""
+        with open(os.path.join(ROOT, "tests", "golden", fixture[0])) as f:
+            case = json.load(f)
+        if fixture[1] is not None:
+            case = case[fixture[1]]
+        n_, m_ = case["n"], case["m"]
+        sec, bl, tape = be32(case["secrets"]), be32(case["blindings"]), bytes.fromhex(case["tape"])
+        coms_ = b"".join(bytes.fromhex(c) for c in case["commitments"])
+        prove = ctx.wip_rangeproof_prove if kind else ctx.rangeproof_prove
+        verify = ctx.wip_rangeproof_verify if kind else ctx.rangeproof_verify
+        pbatch = ctx.wip_rangeproof_prove_batch if kind else ctx.rangeproof_prove_batch
+        proof = prove(gens_x, n_, sec, bl, tape)
+        if proof.hex() != case["proof"]:
+            raise SystemExit("prover: proof bytes differ from the golden fixture %s" % fixture[0])
+        reps = 4
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            prove(gens_x, n_, sec, bl, tape)
+        t_prove = (time.perf_counter() - t0) / reps * 1e3
+        assert verify(gens_x, n_, m_, proof, coms_, 2) == 0
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            verify(gens_x, n_, m_, proof, coms_, 2)
+        t_ver = (time.perf_counter() - t0) / reps * 1e3
+        pbatch(gens_x, n_, m_, sec * 8, bl * 8, tape * 8, len(tape))
+        t0 = time.perf_counter()
+        got = pbatch(gens_x, n_, m_, sec * nb, bl * nb, tape * nb, len(tape))
+        dtb = time.perf_counter() - t0
+        if not (len(got) == nb and got[0] == proof and got[-1] == proof):
+            raise SystemExit("batch prover: proof bytes differ from the golden fixture %s" % fixture[0])
+        return {"fixture": fixture[0], "n": n_, "m": m_, "proof_bytes": len(proof), "prove_ms": t_prove, "aggregated_verify_ms": t_ver,
+                "prove_batch_per_s": nb / dtb, "prove_batch_size": nb,
+                "what": "single-proof latency through the C ABI and batch-prover rate (bp_%srangeproof_prove(_batch)), every proof "
+                        "byte-identical to the oracle-made fixture" % ("wip_" if kind else "")}
+
+    def side_batch(kind, m, P_side, what, fixture=None, nb=64):
         nm = 64 * m
         k = nm.bit_length() - 1
         g2, h2, G2, H2 = ctx.generate_bases(kind, bpa.KZEN_SEED, 64, m)
@@ -874,15 +1056,23 @@ def main():
                "what": what + " (%d distinct GPU-made proofs, 1/16 tampered, verdicts checked)" % P_side}
         if rlc2:
             res["rlc"] = rlc2
+        if fixture and not args.no_prove:
+            res["prover"] = prover_numbers(gens2, kind, fixture, nb)
+        del d_p2, d_c2, d_v4, d_v5
         gens2.close()
         return res
 
-    plus = c2 = msm = None
+    plus = c2 = c4 = msm = prove_c1 = None
+    if world == 1 and not args.no_prove:
+        prove_c1 = prover_numbers(gens, 0, ("bp_cases.json", 3), 512)  # BASELINE.json configs[0]: n=64 m=1 prove (+ verify)
     if world == 1 and not args.no_bpplus:
         plus = side_batch(1, 1, P, "bp_wip_rangeproof_verify_batch_device: RangeProofWIP::aggregated_verify (Bulletproofs+), n=64 m=1")
     if world == 1 and not args.no_c2:
         c2 = side_batch(0, 16, max(256, P // 16), "bp_rangeproof_verify_batch_device at BASELINE.json configs[1]'s shape: "
-                        "RangeProof::aggregated_verify, n=64 m=16")
+                        "RangeProof::aggregated_verify, n=64 m=16", fixture=("bp_c2_n64_m16.json", None), nb=128)
+    if world == 1 and not args.no_c4:
+        c4 = side_batch(1, 64, max(64, P // 64), "bp_wip_rangeproof_verify_batch_device at BASELINE.json configs[3]'s shape: "
+                        "RangeProofWIP::aggregated_verify (range_proof_wip.rs:388-609), n=64 m=64", fixture=("bpplus_c4_n64_m64.json", None), nb=32)
     if world == 1 and not args.no_msm:
         msm = msm_side(ctx, dev, args.msm_log2, max(args.steps, 10))
 
@@ -890,10 +1080,14 @@ def main():
         total_proofs = world * P * args.steps
         value = total_proofs / dt
         msm_ms = kms["bpv_msm"]
+        ev = Evidence()
+        ex_msm, su_msm, ex_at = ev.verify_msm()
+        ex_dec, su_dec = ev.decompress()
         model = MAD32_PER_PROOF_MSM * P / (msm_ms * 1e-3) if msm_ms > 0 else 0.0
-        # the counted figure belongs to the default configuration (>= 65536 proofs per launch: 2 lanes per proof; automatic table window)
-        counted = P >= 65536 and not args.window_bits and not args.lanes and msm_ms > 0
-        executed = EXEC_MAD32_PER_PROOF_MSM * P / (msm_ms * 1e-3) if counted else model
+        # the counted figure belongs to the default configuration (>= 40960 proofs per launch: 2 lanes per proof; automatic table window)
+        counted = P >= 40960 and not args.window_bits and not args.lanes and msm_ms > 0 and ex_msm is not None
+        executed = ex_msm * P / (msm_ms * 1e-3) if counted else model
+        survey = su_msm * P / (msm_ms * 1e-3) if counted else None
         by_count = {r["proofs_per_launch_per_gpu"]: r for r in sweep}
         out = {
             "metric": "verified range proofs/sec (secp256k1, n=64) at 1/2/4/8 GPUs; MSM Mpts/s",
@@ -926,6 +1120,10 @@ def main():
             "rlc_batch": rlc,
             "bpplus_batch": plus,
             "c2_batch": c2,
+            "c4_batch": c4,
+            "prove_c1": prove_c1,
+            "provers": {"configs[0] n=64 m=1": prove_c1, "configs[1] n=64 m=16": (c2 or {}).get("prover"),
+                        "configs[3] BP+ n=64 m=64": (c4 or {}).get("prover")},
             "roofline": {
                 "bound": "valu_int32_mad",
                 "kernel": "k_bpv_fix + k_bpv_msm (the verification MSM: fixed-generator half and proof-specific half, launched back to back)",
@@ -934,27 +1132,33 @@ def main():
                 "unit": "TMAD32/s",
                 "frac": executed / PEAK_MAD32_PER_S,
                 "frac_executed": executed / PEAK_MAD32_PER_S if counted else None,
+                "frac_survey_unit": survey / PEAK_MAD32_PER_S if counted else None,
                 "frac_model": model / PEAK_MAD32_PER_S,
-                "traffic": PMC_TRAFFIC_BYTES_DEFAULT if (P == 65536 and not args.window_bits and not args.lanes) else None,
-                "traffic_unit": "bytes per launch (PMC, profiles/r02_pmc_*.csv)",
-                "executed_mad32_per_proof": EXEC_MAD32_PER_PROOF_MSM if counted else None,
+                "traffic": ev.verify_traffic() if (P == 65536 and not args.window_bits and not args.lanes) else None,
+                "traffic_unit": "bytes per launch pair (PMC passes %s / %s: TCC_EA0 read requests x 64 B + write requests x 64 / 32 B)"
+                                % (ev.files.get("pmc_read"), ev.files.get("pmc_write")),
+                "executed_mad32_per_proof": ex_msm if counted else None,
+                "survey_unit_mad32_per_proof": su_msm if counted else None,
                 "model_mad32_per_proof": MAD32_PER_PROOF_MSM,
-                "what": "frac = frac_executed: v_mad_u64_u32 lane-results the kernel executes per proof (counted by the instrumented build, "
-                        "profiles/r02_opcount.json: field multiplications x 102 + squarings x 65, the v_mad_u64_u32 of their ISA) x proofs / launch time / measured peak; "
-                        "frac_model: SURVEY 8(d)'s Pippenger model (146 points, c=5), which charges doublings and buckets a table-based "
-                        "verifier does not execute, so it is not a bound for this kernel",
+                "evidence_files": ev.files,
+                "what": "frac = frac_executed: v_mad_u64_u32 lane-results the kernels execute per proof - field multiplications x 102 + squarings "
+                        "x 65 (the MADs of the 9x29-limb ISA incl. the reduction), COUNTED by the instrumented build on a %s-proof launch and "
+                        "read from profiles/%s - x proofs / launch time / measured peak; frac_survey_unit: the same counted field operations x "
+                        "64 MAD32, SURVEY 8(d)'s definition of a field multiplication (8x8 schoolbook), i.e. without this implementation's "
+                        "extra limb products; frac_model: SURVEY 8(d)'s Pippenger model (146 points, c=5), which charges doublings and "
+                        "buckets a table-based verifier does not execute, so it is not a bound for this kernel" % (ex_at, ev.files.get("opcount")),
                 "proofs_per_launch": P,
                 "avg_launch_ms": msm_ms,
                 "avg_launch_ms_what": "k_bpv_fix + k_bpv_msm of one call with the GPU to themselves (HIP events on the library's stream, calls "
                                       "one at a time: per-stage timing switches the overlap of successive calls off); agrees with "
-                                      "profiles/r02_bench_kernel_stats_serial.csv (rocprofv3 of bench.py --no-overlap).  In the timed region two "
+                                      "the newest profiles/rNN_bench_kernel_stats_serial.csv (rocprofv3 of bench.py --no-overlap).  In the timed region two "
                                       "calls are in flight and each kernel's wall time stretches while it shares the GPU "
-                                      "(profiles/r02_bench_kernel_stats.csv), so the rate of the whole pipelined step is given beside it",
-                "frac_whole_step": ((EXEC_MAD32_PER_PROOF_MSM + EXEC_MAD32_PER_PROOF_DECOMPRESS) if counted else MAD32_PER_PROOF_MSM)
-                                   * value / world / PEAK_MAD32_PER_S,
+                                      "(profiles/rNN_bench_kernel_stats.csv), so the rate of the whole pipelined step is given beside it",
+                "frac_whole_step": ((ex_msm + (ex_dec or 0.0)) if counted else MAD32_PER_PROOF_MSM) * value / world / PEAK_MAD32_PER_S,
+                "frac_whole_step_survey_unit": ((su_msm + (su_dec or 0.0)) * value / world / PEAK_MAD32_PER_S) if counted else None,
                 "frac_whole_step_what": "counted MADs per proof of the MSM pair AND the decompression (the scalar kernels' mod-q multiplies are "
                                         "not counted) x proofs/s per GPU / peak: the whole pipelined step as the timed region runs it; equals "
-                                        "value x 3.177e6 / peak, so it can be checked against the driver's own clock",
+                                        "value x (executed_mad32_per_proof + decompression) / peak, so it can be checked against the driver's clock",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -4,7 +4,7 @@ INSTRUMENTED build (make -C bulletproofs_amd/csrc opcount -> libbpmsm_opcount.so
 fp_mul / fp_sqr calls) and converts to v_mad_u64_u32 lane-results with the static per-call counts of the ISA
 (fp_mul = 102, fp_sqr = 65 v_mad_u64_u32 per call incl. the reduction; profiles/r02_fp_isa.txt).  Writes one JSON object.
 
-    BPMSM_LIB=bulletproofs_amd/libbpmsm_opcount.so python scripts/opcount.py > profiles/r02_opcount.json
+    BPMSM_LIB=bulletproofs_amd/libbpmsm_opcount.so python scripts/opcount.py > profiles/r03_opcount.json   (bench.py reads the newest)
 """
 import ctypes
 import json
@@ -37,8 +37,9 @@ def main():
     ctx = bpa.Context(0)
     golden = bench.load_batch()
     g_xy, h_xy, G_xy, H_xy = (bytes.fromhex(golden[x]) for x in ("g_vec", "h_vec", "G", "H"))
-    P = int(os.environ.get("OPCOUNT_PROOFS", "8192"))
+    P0 = int(os.environ.get("OPCOUNT_PROOFS", "65536"))  # the headline launch shape (count where the bench runs)
     for wb, lanes in ((0, 2), (0, 16), (16, 2)):
+        P = P0 if (wb, lanes) == (0, 2) else min(P0, 8192)
         gens = bpa.Gens(ctx, g_xy, h_xy, G_xy, H_xy, wb)
         proofs, coms, plen = bench.make_distinct_batch(ctx, gens, G_xy, H_xy, 0, 1, P, b"opcount")
         d_p = torch.frombuffer(bytearray(proofs), dtype=torch.uint8).to(dev)
