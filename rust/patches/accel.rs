@@ -96,3 +96,69 @@ pub fn fold_bases(
         (0..lo.len()).map(|i| &hi[i] * s_hi + &lo[i] * s_lo).collect()
     }
 }
+
+/// init + sum_{bits[i]} g[i] - sum_{!bits[i]} h[i]: the bit commitment A of both provers (range_proof.rs:93-107,
+/// range_proof_wip.rs:152-165).  On the GPU one MSM over g || h with scalars 1 / 0 for g and 0 / q-1 for h.
+pub fn signed_unit_sum(g: &[Point<Secp256k1>], h: &[Point<Secp256k1>], bits: &[bool], init: Point<Secp256k1>) -> Point<Secp256k1> {
+    assert!(g.len() == bits.len() && h.len() == bits.len());
+    #[cfg(feature = "gpu")]
+    {
+        let one = BigInt::from(1u32);
+        let zero = BigInt::from(0u32);
+        let minus_one = Scalar::<Secp256k1>::group_order() - &one;
+        let mut scalars: Vec<BigInt> = bits.iter().map(|b| if *b { one.clone() } else { zero.clone() }).collect();
+        scalars.extend(bits.iter().map(|b| if *b { zero.clone() } else { minus_one.clone() }));
+        let mut points = Vec::with_capacity(2 * bits.len());
+        points.extend_from_slice(g);
+        points.extend_from_slice(h);
+        msm(&points, &scalars, init)
+    }
+    #[cfg(not(feature = "gpu"))]
+    {
+        let acc = g.iter().zip(bits).fold(init, |acc, x| if *x.1 { acc + x.0 } else { acc });
+        h.iter().zip(bits).fold(acc, |acc, x| if !*x.1 { acc - x.0 } else { acc })
+    }
+}
+
+/// out[i] = points[i] * scalars[i]: hi_tag of prove / verify / fast_verify (range_proof.rs:231-233, 327-329, 462-464).
+pub fn scalar_mul_batch(points: &[Point<Secp256k1>], scalars: &[Scalar<Secp256k1>]) -> Vec<Point<Secp256k1>> {
+    assert_eq!(points.len(), scalars.len());
+    #[cfg(feature = "gpu")]
+    {
+        let bn: Vec<BigInt> = scalars.iter().map(|s| s.to_bigint()).collect();
+        gpu::CTX.with(|c| c.scalar_mul_batch(points, &bn)).expect("accel: bp_scalar_mul_batch")
+    }
+    #[cfg(not(feature = "gpu"))]
+    {
+        (0..points.len()).map(|i| &points[i] * &scalars[i]).collect()
+    }
+}
+
+/// `Point::generator() * s`: the point y*G hashed into z (range_proof.rs:125-126).
+pub fn generator_mul(s: &Scalar<Secp256k1>) -> Point<Secp256k1> {
+    #[cfg(feature = "gpu")]
+    {
+        gpu::CTX.with(|c| c.fixed_base_mul(&[s.to_bigint()])).expect("accel: bp_fixed_base_mul_batch").remove(0)
+    }
+    #[cfg(not(feature = "gpu"))]
+    {
+        Point::<Secp256k1>::generator() * s
+    }
+}
+
+/// `base * s` for the caller's G (range_proof.rs:219, 588): the fixed-base kernel when G is the secp256k1 generator (every
+/// reference test and bench), one variable-base multiplication otherwise.
+pub fn fixed_base_mul(base: &Point<Secp256k1>, s: &Scalar<Secp256k1>) -> Point<Secp256k1> {
+    #[cfg(feature = "gpu")]
+    {
+        if *base == Point::<Secp256k1>::generator().to_point() {
+            generator_mul(s)
+        } else {
+            scalar_mul_batch(std::slice::from_ref(base), std::slice::from_ref(s)).remove(0)
+        }
+    }
+    #[cfg(not(feature = "gpu"))]
+    {
+        base * s
+    }
+}

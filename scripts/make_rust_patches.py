@@ -33,12 +33,33 @@ def edits_for(path, lines):
         E.append((j, j - 1, ['pub mod accel;\n']))
     elif path == "src/proofs/range_proof.rs":
         E += sub_random(lines, 57, 58) + sub_random(lines, 110, 113) + sub_random(lines, 164, 165)
+        # A = H*alpha + sum_{bit} g_i - sum_{!bit} h_i   (range_proof.rs:93-107): a signed-unit MSM
+        E.append((93, 107, ["        A = crate::accel::signed_unit_sum(&g_vec, &h_vec, &secret_bits, A);\n"]))
         # S = H*rho + <SL, g> + <SR, h>   (range_proof.rs:116-122)
         E.append((116, 122, [
             "        let SL_bn = SL.iter().map(|s| s.to_bigint()).collect::<Vec<BigInt>>();\n",
             "        let SR_bn = SR.iter().map(|s| s.to_bigint()).collect::<Vec<BigInt>>();\n",
             "        S = crate::accel::msm2(&g_vec, &SL_bn, &h_vec, &SR_bn, S);\n",
             "        let _ = &mut index;\n"]))
+        # y*G with the secp256k1 generator (range_proof.rs:125-126), x_u*G / challenge_x*G with the caller's G (:219, :588)
+        E.append((125, 126, ["        let yG: Point<Secp256k1> = crate::accel::generator_mul(&y);\n"]))
+        E.append((219, 219, ["        let Gx = crate::accel::fixed_base_mul(G, &challenge_x);\n"]))
+        E.append((588, 588, ["        let ux = crate::accel::fixed_base_mul(G, &x_u_fe);\n"]))
+        # hi_tag[i] = h_i * y^-i in prove, verify and fast_verify (range_proof.rs:231-233, 327-329, 462-464)
+        for a in (231, 327, 462):
+            E.append((a, a + 2, ["        let hi_tag = crate::accel::scalar_mul_batch(&h_vec, &yi_inv);\n"]))
+        # P' = P' g^l h'^r (range_proof.rs:236-244): two folds -> one MSM
+        E.append((235, 244, ["        // P' = P' g^l h'^r\n", "        let P = crate::accel::msm2(&g_vec, &Lp, &hi_tag, &Rp, P);\n"]))
+        # verify / fast_verify: P1 = P + <z y^i + z^(2+j) 2^k, hi_tag>, P = P1 + <-z, g_vec> (range_proof.rs:375-391, 510-526):
+        # the closure that forms the scalar is kept (reference lines, taken at generation time), its point product and the two
+        # folds become one MSM
+        for a in (375, 510):
+            body = lines[a:a + 8]  # .map(|i| { ... let zyn_zsq2n = ...;   (lines a+1 .. a+8)
+            E.append((a, a + 16,
+                      ["        let P1_scalars = (0..nm)\n"] + body +
+                      ["                zyn_zsq2n\n", "            })\n", "            .collect::<Vec<BigInt>>();\n",
+                       "        let z_minus_bn = vec![z_minus_fe.to_bigint(); nm];\n",
+                       "        let P = crate::accel::msm2(&hi_tag, &P1_scalars, &g_vec, &z_minus_bn, P);\n"]))
         # aggregated_verify's single multi-exponentiation (range_proof.rs:771-774)
         E.append((771, 774, ["        let lhs = crate::accel::msm(&points, &scalars, H_times_scalar_H);\n"]))
     elif path == "src/proofs/inner_product.rs":
@@ -60,6 +81,11 @@ def edits_for(path, lines):
         E.append((501, 504, ["        let lhs = crate::accel::msm(&points, &scalars, h_delta_prime);\n"]))
     elif path == "src/proofs/range_proof_wip.rs":
         E += sub_random(lines, 150, 150)
+        # A = H*alpha + sum_{bit} g_i - sum_{!bit} h_i   (range_proof_wip.rs:152-165)
+        E.append((152, 165, ["        A = crate::accel::signed_unit_sum(&g_vec, &h_vec, &secret_bits, A);\n"]))
+        # A_hat in prove (:249-251) and in verify (:370-372)
+        E.append((249, 251, ["        let A_hat = crate::accel::msm(&A_hat_bases, &A_hat_scalars, A.clone());\n"]))
+        E.append((370, 372, ["        let A_hat = crate::accel::msm(&A_hat_bases, &A_hat_scalars, sum_com);\n"]))
         E.append((599, 602, ["        let lhs = crate::accel::msm(&points, &scalars, h_delta_prime);\n"]))
     return E
 

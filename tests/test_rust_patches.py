@@ -51,7 +51,7 @@ def test_every_hunk_applies_to_the_reference():
                 assert src[k] == line[1:], "%s: %s line %d: %r != %r" % (os.path.basename(p), path, k + 1, src[k], line[1:])
                 k += 1
             n += 1
-    assert n >= 19
+    assert n >= 30
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
@@ -70,7 +70,7 @@ def test_patches_only_call_what_the_shim_and_wrapper_define():
         for line in open(p).read().splitlines():
             if line.startswith("+") and not line.startswith("+++") and "src/accel.rs" not in line:
                 used |= set(re.findall(r"crate::accel::(\w+)", line))
-    assert used == {"msm", "msm2", "fold_bases", "random_scalar"}
+    assert used == {"msm", "msm2", "fold_bases", "random_scalar", "signed_unit_sum", "scalar_mul_batch", "generator_mul", "fixed_base_mul"}
     for f in used:
         assert re.search(r"pub fn %s\b" % f, shim), f
     for f in re.findall(r"\bc\.(\w+)\(", shim):
@@ -92,3 +92,41 @@ def test_patches_only_call_what_the_shim_and_wrapper_define():
                             if not line.startswith("+"):
                                 k += 1
             assert set(sites) <= patched, (f, sorted(set(sites) - patched))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+def test_every_patch_point_of_integration_md_has_a_hunk():
+    """Every `file:line(-line)` range of INTEGRATION.md section 2's table lies inside the removed lines of some hunk
+    (the patch set covered 6 of the 11 rows)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = doc[doc.index("| file:line | today | becomes |"):doc.index("Two integration depths.")]
+    removed = {}
+    for p in PATCHES:
+        for path, start, body in hunks(open(p).read()):
+            if path == "/dev/null":
+                continue
+            k = start
+            for line in body:
+                if line.startswith("-"):
+                    removed.setdefault(os.path.basename(path), set()).add(k)
+                if not line.startswith("+"):
+                    k += 1
+    rows = 0
+    for row in table.splitlines()[2:]:
+        if not row.startswith("|"):
+            continue
+        cell = row.split("|")[1]
+        fname = None
+        for tok in re.findall(r"`([^`]+)`", cell):
+            for part in tok.split(","):
+                part = part.strip()
+                m = re.match(r"(?:src/proofs/)?(\w+\.rs):(.*)", part)
+                if m:
+                    fname, part = m.group(1), m.group(2)
+                m = re.match(r"(\d+)(?:-(\d+))?$", part.strip())
+                assert m and fname, (row, part)
+                lo, hi = int(m.group(1)), int(m.group(2) or m.group(1))
+                hit = [n for n in range(lo, hi + 1) if n in removed.get(fname, set())]
+                assert hit, "no hunk removes a line of %s:%d-%d" % (fname, lo, hi)
+        rows += 1
+    assert rows >= 11
