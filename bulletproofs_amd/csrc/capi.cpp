@@ -402,6 +402,8 @@ int bp_ctx_create(int device, bp_ctx** out) {
 
 void bp_ctx_destroy(bp_ctx* ctx) {
     if (!ctx) return;
+    for (bp_ctx* sub : ctx->prove_lanes) bp_ctx_destroy(sub);
+    ctx->prove_lanes.clear();
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->vside) (void)hipStreamSynchronize(ctx->vside);  // the verifier's side lane may still be running

@@ -1673,6 +1673,184 @@ int bp_wipa_verify(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* hi_tag_xy, s
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Device batch prover (Bulletproofs): the per-proof vectors live on the GPU (prove_kernels.hip), the table MSMs of every
+// step are ONE k_bpv_fix launch for the whole batch, and this host loop keeps only what the reference's transcript needs:
+// it hashes the points a step returns into the next challenge (range_proof.rs:124-127, 171, 214-218; inner_product.rs:117)
+// and encodes the proofs.  Steps: A,S -> y -> yG -> z -> T1,T2 -> x -> (tau_x, miu, tx) -> x_u -> Gx -> k rounds (L_j, R_j -> x_j).
+// Returns BP_OK with st[i] = BP_EINVAL for a proof the single-proof code refuses (bad tape, identity point, zero challenge).
+}  // extern "C"
+namespace {
+
+template <class F>
+void parallel_for(size_t n, F fn) {  // the per-proof SHA-256 of a step: a few host threads once the batch is large
+    const size_t nthr = n >= 512 ? 8 : (n >= 128 ? 4 : 1);
+    if (nthr == 1) {
+        for (size_t i = 0; i < n; i++) fn(i);
+        return;
+    }
+    std::vector<std::thread> thr;
+    for (size_t t = 0; t < nthr; t++)
+        thr.emplace_back([=] {
+            for (size_t i = t; i < n; i += nthr) fn(i);
+        });
+    for (auto& t : thr) t.join();
+}
+
+int prove_batch_device_chunk(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, size_t N, const uint8_t* secrets_be, const uint8_t* blindings_be,
+                             const uint8_t* tapes, size_t tape_len, uint8_t* proofs_out, size_t proof_len, int* st) {
+    const size_t n = (size_t)n_bits, nm = n * (size_t)m, NT = 2 * nm + 2;
+    const int k = log2_exact(nm), W = gens->W, c = gens->c;
+    hipStream_t s = ctx->stream;
+    // device workspace, carved from one buffer
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const size_t o_tape = carve(N * tape_len), o_bits = carve(N * nm), o_blind = carve(N * (size_t)m * 32), o_SL = carve(N * nm * sizeof(fqm)),
+                 o_SR = carve(N * nm * sizeof(fqm)), o_yi = carve(N * nm * sizeof(fqm)), o_a = carve(N * nm * sizeof(fqm)),
+                 o_b = carve(N * nm * sizeof(fqm)), o_cG = carve(N * nm * sizeof(fqm)), o_cH = carve(N * nm * sizeof(fqm)),
+                 o_zpow = carve(N * (size_t)m * sizeof(fqm)), o_yinv = carve(N * sizeof(fqm)), o_dig = carve(2 * N * NT * (size_t)W * sizeof(tdig_t)),
+                 o_bad = carve(2 * N * sizeof(int)), o_res = carve(2 * N * sizeof(xyzz)), o_aff = carve(2 * N * sizeof(affine_mem)),
+                 o_ptbe = carve(2 * N * 64), o_yz = carve(N * 64), o_x = carve(N * 32), o_xu = carve(N * 32), o_xj = carve(N * 32),
+                 o_out = carve(N * 96);
+    RC(ctx->proto[0].reserve(off));
+    uint8_t* D = (uint8_t*)ctx->proto[0].p;
+    const size_t pin_bytes = 2 * N * 64 + N * 96 + N * 64 + N * nm;
+    RC(pin_reserve(ctx, pin_bytes));
+    uint8_t* h_pts = (uint8_t*)ctx->h_pin;    // [2N][64] points of a step
+    uint8_t* h_sc = h_pts + 2 * N * 64;       // [N][96] scalars down / [N][64] challenges up
+    uint8_t* h_up = h_sc + N * 96;            // [N][64]
+    uint8_t* h_bits = h_up + N * 64;          // [N][nm]
+    std::vector<uint8_t> ok(N, 1);
+    // tape scalars must be canonical and non-zero (Tape::next); the aggregated secret's bits (range_proof.rs:70-91)
+    parallel_for(N, [&](size_t i) {
+        const uint8_t* tp = tapes + i * tape_len;
+        for (size_t j = 0; j < 2 * nm + 4; j++) {
+            const uint8_t* q = tp + 32 * j;
+            bool z = true;
+            for (int b = 0; b < 32; b++) z = z && q[b] == 0;
+            if (z || !fq_be_is_canonical(q)) ok[i] = 0;
+        }
+        std::vector<int> bits = secret_bits(secrets_be + i * (size_t)m * 32, m, n);
+        for (size_t j = 0; j < nm; j++) h_bits[i * nm + j] = (uint8_t)bits[j];
+    });
+    HIPCHK(hipMemcpyAsync(D + o_tape, tapes, N * tape_len, hipMemcpyHostToDevice, s), "h2d tapes");
+    HIPCHK(hipMemcpyAsync(D + o_bits, h_bits, N * nm, hipMemcpyHostToDevice, s), "h2d bits");
+    HIPCHK(hipMemcpyAsync(D + o_blind, blindings_be, N * (size_t)m * 32, hipMemcpyHostToDevice, s), "h2d blindings");
+    HIPCHK(hipMemsetAsync(D + o_bad, 0, 2 * N * sizeof(int), s), "memset");
+    fqm *SL = (fqm*)(D + o_SL), *SR = (fqm*)(D + o_SR), *yi = (fqm*)(D + o_yi), *a = (fqm*)(D + o_a), *b = (fqm*)(D + o_b), *cG = (fqm*)(D + o_cG),
+        *cH = (fqm*)(D + o_cH), *zpow = (fqm*)(D + o_zpow), *yinv = (fqm*)(D + o_yinv);
+    tdig_t* dig = (tdig_t*)(D + o_dig);
+    // the table MSMs of one step: njobs dense digit arrays -> affine big-endian points on the host
+    auto msm_step = [&](size_t njobs) -> int {
+        HIPCHK(launch_bpv_fix_jobs((int)nm, njobs, gens->d_table, c, W, dig, (const int*)(D + o_bad), (xyzz*)(D + o_res), s), "table msm");
+        HIPCHK(launch_xyzz_to_affine((const xyzz*)(D + o_res), (affine_mem*)(D + o_aff), njobs, s), "normalize");
+        HIPCHK(launch_export_points((const affine_mem*)(D + o_aff), D + o_ptbe, njobs, s), "export");
+        HIPCHK(hipMemcpyAsync(h_pts, D + o_ptbe, njobs * 64, hipMemcpyDeviceToHost, s), "d2h points");
+        HIPCHK(hipStreamSynchronize(s), "sync");
+        return BP_OK;
+    };
+    auto inf = [](const uint8_t* p) { return host_is_inf(p); };
+    std::vector<Pt> A(N), S(N), T1(N), T2(N), ux(N);
+    std::vector<Fq> y(N), z(N), xu(N);
+    std::vector<uint8_t> sc3(N * 96);
+    std::vector<std::vector<Pt>> Ls(N, std::vector<Pt>(k)), Rs(N, std::vector<Pt>(k));
+    // A, S   (:93-122)
+    HIPCHK(launch_pv_init(N, (int)nm, c, W, D + o_tape, tape_len, D + o_bits, SL, SR, dig, s), "pv_init");
+    RC(msm_step(2 * N));
+    parallel_for(N, [&](size_t i) {
+        memcpy(A[i].b, h_pts + 128 * i, 64);
+        memcpy(S[i].b, h_pts + 128 * i + 64, 64);
+        if (inf(A[i].b) || inf(S[i].b)) ok[i] = 0;
+        y[i] = Transcript().point(A[i].b).point(S[i].b).result_scalar();  // :124
+        if (y[i].is_zero()) ok[i] = 0;
+        (ok[i] ? y[i] : Fq(1)).to_be(h_up + 32 * i);
+    });
+    // yG = Point::generator() * y, z = H(yG)   (:125-127)
+    HIPCHK(hipMemcpyAsync(D + o_x, h_up, N * 32, hipMemcpyHostToDevice, s), "h2d y");
+    HIPCHK(launch_pv_term(N, (int)nm, c, W, gens->ibase, D + o_x, dig, s), "pv_term");
+    RC(msm_step(N));
+    parallel_for(N, [&](size_t i) {
+        if (inf(h_pts + 64 * i)) ok[i] = 0;
+        z[i] = Transcript().point(h_pts + 64 * i).result_scalar();
+        (ok[i] ? y[i] : Fq(1)).to_be(h_up + 64 * i);
+        z[i].to_be(h_up + 64 * i + 32);
+    });
+    // t1, t2, T1, T2   (:131-169)
+    HIPCHK(hipMemcpyAsync(D + o_yz, h_up, N * 64, hipMemcpyHostToDevice, s), "h2d yz");
+    HIPCHK(launch_pv_poly(N, n_bits, m, c, W, D + o_tape, tape_len, D + o_yz, D + o_bits, SL, SR, yi, zpow, yinv, dig, s), "pv_poly");
+    RC(msm_step(2 * N));
+    const uint8_t* Gh = &gens->host_be[2 * nm * 64];
+    const uint8_t* Hh = &gens->host_be[(2 * nm + 1) * 64];
+    parallel_for(N, [&](size_t i) {
+        memcpy(T1[i].b, h_pts + 128 * i, 64);
+        memcpy(T2[i].b, h_pts + 128 * i + 64, 64);
+        if (inf(T1[i].b) || inf(T2[i].b)) ok[i] = 0;
+        Transcript().point(T1[i].b).point(T2[i].b).point(Gh).point(Hh).result_scalar().to_be(h_up + 32 * i);  // x, :171
+    });
+    // Lp, Rp, tx, tau_x, miu   (:171-212), then x_u and Gx   (:214-219)
+    HIPCHK(hipMemcpyAsync(D + o_x, h_up, N * 32, hipMemcpyHostToDevice, s), "h2d x");
+    HIPCHK(launch_pv_lr(N, n_bits, m, D + o_tape, tape_len, D + o_yz, D + o_x, D + o_blind, D + o_bits, SL, SR, yi, zpow, yinv, a, b, cG, cH, D + o_out,
+                        s),
+           "pv_lr");
+    HIPCHK(hipMemcpyAsync(h_sc, D + o_out, N * 96, hipMemcpyDeviceToHost, s), "d2h scalars");
+    HIPCHK(hipStreamSynchronize(s), "sync");
+    parallel_for(N, [&](size_t i) {
+        memcpy(&sc3[96 * i], h_sc + 96 * i, 96);
+        xu[i] = Transcript().bigint32(h_sc + 96 * i).bigint32(h_sc + 96 * i + 32).bigint32(h_sc + 96 * i + 64).result_scalar();
+        xu[i].to_be(h_up + 32 * i);
+    });
+    HIPCHK(hipMemcpyAsync(D + o_xu, h_up, N * 32, hipMemcpyHostToDevice, s), "h2d xu");
+    HIPCHK(launch_pv_term(N, (int)nm, c, W, (int)(2 * nm), D + o_xu, dig, s), "pv_term");
+    RC(msm_step(N));
+    for (size_t i = 0; i < N; i++) {
+        memcpy(ux[i].b, h_pts + 64 * i, 64);
+        if (inf(ux[i].b)) ok[i] = 0;
+    }
+    // InnerProductArg::prove   (inner_product.rs:36-169)
+    size_t len = nm;
+    for (int j = 0; j < k; j++, len /= 2) {
+        HIPCHK(launch_pv_round(N, (int)nm, (int)len, c, W, D + o_xu, a, b, cG, cH, dig, s), "pv_round");
+        RC(msm_step(2 * N));
+        parallel_for(N, [&](size_t i) {
+            memcpy(Ls[i][j].b, h_pts + 128 * i, 64);
+            memcpy(Rs[i][j].b, h_pts + 128 * i + 64, 64);
+            if (inf(Ls[i][j].b) || inf(Rs[i][j].b)) ok[i] = 0;
+            Fq x = Transcript().point(Ls[i][j].b).point(Rs[i][j].b).point(ux[i].b).result_scalar();  // :117
+            if (x.is_zero()) ok[i] = 0;
+            (x.is_zero() ? Fq(1) : x).to_be(h_up + 32 * i);
+        });
+        HIPCHK(hipMemcpyAsync(D + o_xj, h_up, N * 32, hipMemcpyHostToDevice, s), "h2d xj");
+        HIPCHK(launch_pv_fold(N, (int)nm, (int)len, D + o_xj, a, b, cG, cH, s), "pv_fold");
+        if (j + 1 < k) HIPCHK(hipStreamSynchronize(s), "sync");  // h_up is rewritten by the next round
+    }
+    HIPCHK(launch_pv_final(N, (int)nm, a, b, D + o_ptbe, s), "pv_final");
+    HIPCHK(hipMemcpyAsync(h_pts, D + o_ptbe, N * 64, hipMemcpyDeviceToHost, s), "d2h ab");
+    HIPCHK(hipStreamSynchronize(s), "sync");
+    parallel_for(N, [&](size_t i) {
+        if (!ok[i]) {
+            st[i] = BP_EINVAL;
+            return;
+        }
+        uint8_t* q = proofs_out + i * proof_len;
+        const Pt* pp[4] = {&A[i], &S[i], &T1[i], &T2[i]};
+        for (int t = 0; t < 4; t++, q += 33) host_compress(pp[t]->b, q);
+        memcpy(q, &sc3[96 * i], 96);  // tau_x, miu, tx
+        q += 96;
+        for (int j = 0; j < k; j++, q += 33) host_compress(Ls[i][j].b, q);
+        for (int j = 0; j < k; j++, q += 33) host_compress(Rs[i][j].b, q);
+        memcpy(q, h_pts + 64 * i, 64);  // a, b
+        st[i] = BP_OK;
+    });
+    return BP_OK;
+}
+
+}  // namespace
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------
 // Batch provers: N independent proofs over the same generators.  Every proof runs the single-proof code above on its
 // own host thread; their table-MSM calls are merged into one GPU launch per protocol step (FbBatcher).
 static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, size_t nproofs, const uint8_t* secrets_be,
@@ -1693,13 +1871,50 @@ static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
         return BP_EINVAL;
     }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    size_t kChunk = 128;  // proofs (host threads) in flight
+    // Bulletproofs on the device: the per-proof vectors are kernels over [proof][i] (prove_kernels.hip), the host keeps the
+    // transcript.  (Bulletproofs+ and generators whose G is not the secp256k1 generator keep the host-thread path below.)
+    if (!wip && nm <= 4096 && !bp_tune("BP_PROVE_HOST")) {
+        size_t chunk = ((size_t)1 << 20) / nm;
+        if (chunk > 4096) chunk = 4096;
+        if (chunk < 32) chunk = 32;
+        int first = BP_OK;
+        std::vector<int> stv(nproofs, BP_OK);
+        for (size_t base = 0; base < nproofs; base += chunk) {
+            const size_t cnt = nproofs - base < chunk ? nproofs - base : chunk;
+            int rc = prove_batch_device_chunk(ctx, gens, n_bits, m, cnt, secrets_be + base * (size_t)m * 32, blindings_be + base * (size_t)m * 32,
+                                              tapes + base * tape_len, tape_len, proofs_out + base * proof_len, proof_len, &stv[base]);
+            if (rc != BP_OK) return rc;
+        }
+        for (size_t i = 0; i < nproofs; i++) {
+            if (status) status[i] = stv[i];
+            if (stv[i] != BP_OK && first == BP_OK) first = stv[i];
+        }
+        if (first != BP_OK) set_error_msg("prove_batch: at least one proof failed (see the per-proof status codes)");
+        return first;
+    }
+    size_t kChunk = (nproofs + 3) / 4;  // proofs (host threads) of one rendezvous group: four groups in flight when the batch allows
+    if (kChunk > 128) kChunk = 128;
+    if (kChunk < 16) kChunk = 16;
     if (const char* e = bp_tune("BP_PROVE_CHUNK")) kChunk = (size_t)atol(e) >= 1 && (size_t)atol(e) <= 1024 ? (size_t)atol(e) : kChunk;
+    // Several rendezvous groups IN FLIGHT: a group's protocol step is one packing pass by one host thread, one launch and
+    // one synchronisation (~1 ms for 128 n=64 m=1 proofs, of which the GPU works a fraction); with one group at a time the
+    // other host cores and the GPU idle through it.  Group g runs on lane g mod L, every lane owns a context of its own
+    // (stream, pinned staging, workspaces; created once, kept by `ctx`), so the lanes' steps overlap on the GPU and on the host.
+    size_t kLanes = 4;
+    if (const char* e = bp_tune("BP_PROVE_LANES")) kLanes = (size_t)atol(e) >= 1 && (size_t)atol(e) <= 8 ? (size_t)atol(e) : kLanes;
+    const size_t ngroups = (nproofs + kChunk - 1) / kChunk;
+    if (kLanes > ngroups) kLanes = ngroups;
+    while (ctx->prove_lanes.size() + 1 < kLanes) {  // lane 0 is `ctx` itself
+        bp_ctx* sub = nullptr;
+        int rc = bp_ctx_create(ctx->device, &sub);
+        if (rc != BP_OK) return rc;
+        ctx->prove_lanes.push_back(sub);
+    }
     int first_err = BP_OK;
     std::vector<int> st(nproofs, BP_OK);
-    for (size_t base = 0; base < nproofs; base += kChunk) {
+    auto run_group = [&](bp_ctx* lctx, size_t base) {
         const size_t cnt = nproofs - base < kChunk ? nproofs - base : kChunk;
-        FbBatcher b(ctx, gens);
+        FbBatcher b(lctx, gens);
         b.active = (int)cnt;
         b.pj.reserve(cnt);  // submit() then never allocates
         b.po.reserve(cnt);
@@ -1715,8 +1930,8 @@ static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
                     const uint8_t* bl = blindings_be + i * (size_t)m * 32;
                     const uint8_t* tp = tapes + i * tape_len;
                     uint8_t* out = proofs_out + i * proof_len;
-                    st[i] = wip ? bp_wip_rangeproof_prove(ctx, gens, n_bits, sec, bl, m, tp, tape_len, out, proof_len, &len)
-                                : bp_rangeproof_prove(ctx, gens, n_bits, sec, bl, m, tp, tape_len, out, proof_len, &len);
+                    st[i] = wip ? bp_wip_rangeproof_prove(lctx, gens, n_bits, sec, bl, m, tp, tape_len, out, proof_len, &len)
+                                : bp_rangeproof_prove(lctx, gens, n_bits, sec, bl, m, tp, tape_len, out, proof_len, &len);
                 } catch (...) {  // e.g. std::bad_alloc in the host scalar work: this proof fails, the others go on
                     st[i] = BP_ENOMEM;
                 }
@@ -1734,6 +1949,19 @@ static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
             }
         }
         for (auto& t : thr) t.join();
+    };
+    if (kLanes <= 1) {
+        for (size_t base = 0; base < nproofs; base += kChunk) run_group(ctx, base);
+    } else {
+        std::vector<std::thread> lanes;
+        for (size_t l = 0; l < kLanes; l++) {
+            bp_ctx* lctx = l == 0 ? ctx : ctx->prove_lanes[l - 1];
+            lanes.emplace_back([&, l, lctx] {
+                (void)hipSetDevice(ctx->device);
+                for (size_t g = l; g < ngroups; g += kLanes) run_group(lctx, g * kChunk);
+            });
+        }
+        for (auto& t : lanes) t.join();
     }
     for (size_t i = 0; i < nproofs; i++) {
         if (status) status[i] = st[i];

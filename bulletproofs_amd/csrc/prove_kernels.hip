@@ -1,0 +1,331 @@
+// Scalar side of the BATCH prover `RangeProof::prove` x N on the device
+// (/root/reference/src/proofs/range_proof.rs:45-263, inner_product.rs:36-169): every per-proof vector of the reference's
+// single-threaded prover - the bit vectors aL / aR (:81-83), yi (:131-133), the polynomial coefficients t1 / t2 (:135-162),
+// Lp / Rp / tx (:186-211), and, per inner-product round, c_L / c_R (:64-65), the folds of a and b (:122-137) and the
+// coefficient vectors that replace the folded bases (G^(j)[i] = sum_{t = i mod n'} cG[t] g_t) - is a kernel
+// over [proof][i] on the reduced-radix Montgomery form `fqm` (fq.h), the way verify_scalars.hip does it for the verifier.
+// The kernels write the window digits of the table MSMs (k_bpv_fix, verify_kernels.hip: dense [job][(2nm+2) W] digit
+// arrays, two jobs per proof) directly; the host keeps only the Fiat-Shamir transcript (SHA-256 of the points each step
+// returns) and the proof encoding.  Same values mod q, same group elements, hence the same proof bytes as the host path
+// (tests/test_gpu_proto.py::test_prove_batch_*).
+#include <hip/hip_runtime.h>
+
+#include "ec.h"
+#include "fq.h"
+#include "kernels.h"
+
+namespace bp {
+
+#define PV_T 256  // most lanes of a per-proof workgroup (strided over i; 64 or 128 for short vectors: pv_lanes)
+static unsigned pv_lanes(int nm) { return nm <= 64 ? 64u : (nm <= 128 ? 128u : (unsigned)PV_T); }
+
+__device__ __forceinline__ void pv_store_digits(const fq& kk, int c, int W, tdig_t* __restrict__ out) {
+    const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+        const int bit = w * c;
+        uint32_t v = 0;
+        if (bit < 256) {
+            const int limb = bit >> 5, sh = bit & 31;
+            uint64_t two = kk.v[limb];
+            if (limb + 1 < 8) two |= (uint64_t)kk.v[limb + 1] << 32;
+            v = (uint32_t)(two >> sh) & mask;
+        }
+        v += carry;
+        if (v > half) {
+            carry = 1;
+            out[w] = (tdig_t)((int)v - (int)(1u << c));
+        } else {
+            carry = 0;
+            out[w] = (tdig_t)v;
+        }
+    }
+}
+__device__ __forceinline__ void pv_digits(const fqm& s, int c, int W, tdig_t* __restrict__ out) { pv_store_digits(fqm_to_fq(s), c, W, out); }
+__device__ __forceinline__ void pv_zero(int W, tdig_t* __restrict__ out) {
+    for (int w = 0; w < W; w++) out[w] = 0;
+}
+__device__ __forceinline__ void pv_unit(int W, tdig_t* __restrict__ out, int d) {  // the scalar d = -1, 0 or 1: one digit
+    out[0] = (tdig_t)d;
+    for (int w = 1; w < W; w++) out[w] = 0;
+}
+__device__ __forceinline__ fqm pv_be(const uint8_t* be32) { return fqm_from_fq(fq_from_be_reduce(be32)); }
+__device__ __forceinline__ fqm pv_pow(fqm base, uint32_t e) {
+    fqm r = fqm_one();
+    while (e) {
+        if (e & 1u) r = fqm_mul(r, base);
+        e >>= 1;
+        if (e) base = fqm_mul(base, base);
+    }
+    return r;
+}
+// 2^r (r < 261) in Montgomery form: the plain limb pattern times R^2
+__device__ __forceinline__ fqm pv_two_pow(int r) {
+    fqm t = fqm_zero();
+    t.v[r / 29] = 1u << (r % 29);
+    return fqm_mul(t, fqm_r2());
+}
+// sum of v over the workgroup's lanes, returned to every lane
+__device__ __forceinline__ fqm pv_block_sum(fqm v, fqm* red) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int off = (int)blockDim.x / 2; off >= 1; off >>= 1) {
+        if (tid < off) red[tid] = fqm_add(red[tid], red[tid + off]);
+        __syncthreads();
+    }
+    return red[0];
+}
+
+// Tape of a proof (32-byte big-endian scalars in the reference's draw order, range_proof.rs:57-58, 109-114, 164-165):
+//   alpha, rho, SR[0..nm), SL[0..nm), tau1, tau2
+#define TP_ALPHA 0
+#define TP_RHO 1
+#define TP_SR(i) (2 + (i))
+#define TP_SL(nm, i) (2 + (nm) + (i))
+#define TP_TAU1(nm) (2 + 2 * (nm))
+#define TP_TAU2(nm) (3 + 2 * (nm))
+
+// A = alpha H + sum_{bit} g_i - sum_{!bit} h_i (:93-107) and S = rho H + sum SL_i g_i + SR_i h_i (:116-122): digits of the
+// two jobs of proof pr (jobs 2 pr, 2 pr + 1); SL, SR kept as fqm for the later steps.
+__global__ __launch_bounds__(PV_T) void k_pv_init(int nm, int c, int W, const uint8_t* __restrict__ tapes, size_t tape_len,
+                                                  const uint8_t* __restrict__ bits, fqm* __restrict__ SL, fqm* __restrict__ SR,
+                                                  tdig_t* __restrict__ dig) {
+    const size_t pr = blockIdx.x;
+    const int NT = 2 * nm + 2;
+    const uint8_t* tp = tapes + pr * tape_len;
+    tdig_t* dA = dig + (2 * pr) * (size_t)NT * W;
+    tdig_t* dS = dig + (2 * pr + 1) * (size_t)NT * W;
+    for (int i = threadIdx.x; i < nm; i += (int)blockDim.x) {
+        const fqm sr = pv_be(tp + 32 * (size_t)TP_SR(i)), sl = pv_be(tp + 32 * (size_t)TP_SL(nm, i));
+        SR[pr * nm + i] = sr;
+        SL[pr * nm + i] = sl;
+        const int bit = bits[pr * nm + i];
+        pv_unit(W, dA + (size_t)i * W, bit ? 1 : 0);
+        pv_unit(W, dA + (size_t)(nm + i) * W, bit ? 0 : -1);
+        pv_digits(sl, c, W, dS + (size_t)i * W);
+        pv_digits(sr, c, W, dS + (size_t)(nm + i) * W);
+    }
+    if (threadIdx.x == 0) {
+        pv_zero(W, dA + (size_t)(2 * nm) * W);
+        pv_zero(W, dS + (size_t)(2 * nm) * W);
+        pv_digits(pv_be(tp + 32 * TP_ALPHA), c, W, dA + (size_t)(2 * nm + 1) * W);
+        pv_digits(pv_be(tp + 32 * TP_RHO), c, W, dS + (size_t)(2 * nm + 1) * W);
+    }
+}
+
+// one job per proof with ONE term: scalars[pr] times table row `row` (y * generator :126, x_u * G :219)
+__global__ __launch_bounds__(PV_T) void k_pv_term(int nm, int c, int W, int row, const uint8_t* __restrict__ scalars_be, tdig_t* __restrict__ dig) {
+    const size_t pr = blockIdx.x;
+    const int NT = 2 * nm + 2;
+    tdig_t* d = dig + pr * (size_t)NT * W;
+    for (int t = threadIdx.x; t < NT; t += (int)blockDim.x) {
+        if (t == row)
+            pv_digits(pv_be(scalars_be + 32 * pr), c, W, d + (size_t)t * W);
+        else
+            pv_zero(W, d + (size_t)t * W);
+    }
+}
+
+// yi, z powers, t1, t2 (:131-162) and the digits of T1 = t1 G + tau1 H, T2 = t2 G + tau2 H (:168-169); y^-1 for hi_tag
+__global__ __launch_bounds__(PV_T) void k_pv_poly(int n_bits, int m, int c, int W, const uint8_t* __restrict__ tapes, size_t tape_len,
+                                                  const uint8_t* __restrict__ yz_be /* [N][2][32] */, const uint8_t* __restrict__ bits,
+                                                  const fqm* __restrict__ SL, const fqm* __restrict__ SR, fqm* __restrict__ yi,
+                                                  fqm* __restrict__ zpow /* [N][m] */, fqm* __restrict__ yinv, tdig_t* __restrict__ dig) {
+    __shared__ fqm red[PV_T];
+    const size_t pr = blockIdx.x;
+    const int nm = n_bits * m, NT = 2 * nm + 2;
+    const fqm y = pv_be(yz_be + 64 * pr), z = pv_be(yz_be + 64 * pr + 32), ONE = fqm_one();
+    fqm t1 = fqm_zero(), t2 = fqm_zero();
+    for (int i = threadIdx.x; i < nm; i += (int)blockDim.x) {
+        const fqm yp = pv_pow(y, (uint32_t)i);
+        yi[pr * nm + i] = yp;
+        const fqm sl = SL[pr * nm + i], sr = SR[pr * nm + i];
+        const fqm aL = bits[pr * nm + i] ? ONE : fqm_zero(), aR = fqm_sub(aL, ONE);
+        const fqm sry = fqm_mul(sr, yp);
+        t2 = fqm_add(t2, fqm_mul(sry, sl));                                              // :135-137
+        const fqm zj2k = fqm_mul(pv_pow(z, 2u + (uint32_t)(i / n_bits)), pv_two_pow(i % n_bits));
+        fqm term = fqm_mul(sl, fqm_mul(fqm_add(aR, z), yp));
+        term = fqm_add(term, fqm_mul(fqm_sub(aL, z), sry));
+        term = fqm_add(term, fqm_mul(zj2k, sl));
+        t1 = fqm_add(t1, term);                                                          // :145-162
+    }
+    t1 = pv_block_sum(t1, red);
+    t2 = pv_block_sum(t2, red);
+    tdig_t* d1 = dig + (2 * pr) * (size_t)NT * W;
+    tdig_t* d2 = dig + (2 * pr + 1) * (size_t)NT * W;
+    for (int t = threadIdx.x; t < 2 * nm; t += (int)blockDim.x) {
+        pv_zero(W, d1 + (size_t)t * W);
+        pv_zero(W, d2 + (size_t)t * W);
+    }
+    if (threadIdx.x == 0) {
+        const uint8_t* tp = tapes + pr * tape_len;
+        pv_digits(t1, c, W, d1 + (size_t)(2 * nm) * W);
+        pv_digits(pv_be(tp + 32 * (size_t)TP_TAU1(nm)), c, W, d1 + (size_t)(2 * nm + 1) * W);
+        pv_digits(t2, c, W, d2 + (size_t)(2 * nm) * W);
+        pv_digits(pv_be(tp + 32 * (size_t)TP_TAU2(nm)), c, W, d2 + (size_t)(2 * nm + 1) * W);
+        fqm zp = fqm_mul(z, z);
+        for (int j = 0; j < m; j++) {
+            zpow[pr * m + j] = zp;
+            zp = fqm_mul(zp, z);
+        }
+        yinv[pr] = fqm_inv_var(y);  // (y = 0 is refused by the host before this launch)
+    }
+}
+
+// Lp, Rp, tx, tau_x, miu (:171-212) -> a, b of the inner-product argument; cG = 1, cH = y^-i (hi_tag, :223-233)
+__global__ __launch_bounds__(PV_T) void k_pv_lr(int n_bits, int m, const uint8_t* __restrict__ tapes, size_t tape_len,
+                                                const uint8_t* __restrict__ yz_be, const uint8_t* __restrict__ x_be,
+                                                const uint8_t* __restrict__ blindings_be, const uint8_t* __restrict__ bits,
+                                                const fqm* __restrict__ SL, const fqm* __restrict__ SR, const fqm* __restrict__ yi,
+                                                const fqm* __restrict__ zpow, const fqm* __restrict__ yinv, fqm* __restrict__ a, fqm* __restrict__ b,
+                                                fqm* __restrict__ cG, fqm* __restrict__ cH, uint8_t* __restrict__ out_be /* [N][96] */) {
+    __shared__ fqm red[PV_T];
+    const size_t pr = blockIdx.x;
+    const int nm = n_bits * m;
+    const fqm z = pv_be(yz_be + 64 * pr + 32), x = pv_be(x_be + 32 * pr), ONE = fqm_one(), yv = yinv[pr];
+    fqm tx = fqm_zero();
+    for (int i = threadIdx.x; i < nm; i += (int)blockDim.x) {
+        const fqm sl = SL[pr * nm + i], sr = SR[pr * nm + i], yp = yi[pr * nm + i];
+        const fqm aL = bits[pr * nm + i] ? ONE : fqm_zero(), aR = fqm_sub(aL, ONE);
+        const fqm Lp = fqm_add(fqm_mul(sl, x), fqm_sub(aL, z));                                           // :186-192
+        const fqm zj2k = fqm_mul(zpow[pr * m + i / n_bits], pv_two_pow(i % n_bits));
+        const fqm Rp = fqm_add(fqm_mul(yp, fqm_add(fqm_add(z, aR), fqm_mul(sr, x))), zj2k);               // :194-207
+        a[pr * nm + i] = Lp;
+        b[pr * nm + i] = Rp;
+        tx = fqm_add(tx, fqm_mul(Lp, Rp));                                                                // :208-211
+        cG[pr * nm + i] = ONE;
+        cH[pr * nm + i] = pv_pow(yv, (uint32_t)i);
+    }
+    tx = pv_block_sum(tx, red);
+    if (threadIdx.x == 0) {
+        const uint8_t* tp = tapes + pr * tape_len;
+        const fqm tau1 = pv_be(tp + 32 * (size_t)TP_TAU1(nm)), tau2 = pv_be(tp + 32 * (size_t)TP_TAU2(nm));
+        fqm tau_x = fqm_add(fqm_mul(x, tau1), fqm_mul(fqm_mul(x, x), tau2));
+        for (int j = 0; j < m; j++) tau_x = fqm_add(tau_x, fqm_mul(zpow[pr * m + j], pv_be(blindings_be + 32 * (pr * m + j))));   // :175-183
+        const fqm miu = fqm_add(fqm_mul(pv_be(tp + 32 * TP_RHO), x), pv_be(tp + 32 * TP_ALPHA));                                // :184
+        fq_to_be(out_be + 96 * pr, fqm_to_fq(tau_x));
+        fq_to_be(out_be + 96 * pr + 32, fqm_to_fq(miu));
+        fq_to_be(out_be + 96 * pr + 64, fqm_to_fq(tx));
+    }
+}
+
+// One inner-product round over the ORIGINAL generators (n = current length, h = n / 2): c_L, c_R (inner_product.rs:64-65) and
+// the digits of  L = <a_L, G_R> + <b_R, H_L> + c_L ux (:70-90),  R = <a_R, G_L> + <b_L, H_R> + c_R ux (:95-115)  with
+// G^(j), H^(j) written through the coefficient vectors cG, cH; ux = xu * G, so its term is the scalar c xu on G's row.
+__global__ __launch_bounds__(PV_T) void k_pv_round(int nm, int n, int c, int W, const uint8_t* __restrict__ xu_be, const fqm* __restrict__ a,
+                                                   const fqm* __restrict__ b, const fqm* __restrict__ cG, const fqm* __restrict__ cH,
+                                                   tdig_t* __restrict__ dig) {
+    __shared__ fqm red[PV_T];
+    const size_t pr = blockIdx.x;
+    const int h = n / 2, NT = 2 * nm + 2;
+    const fqm* A = a + pr * nm;
+    const fqm* B = b + pr * nm;
+    fqm cL = fqm_zero(), cR = fqm_zero();
+    for (int i = threadIdx.x; i < h; i += (int)blockDim.x) {
+        cL = fqm_add(cL, fqm_mul(A[i], B[h + i]));
+        cR = fqm_add(cR, fqm_mul(A[h + i], B[i]));
+    }
+    cL = pv_block_sum(cL, red);
+    cR = pv_block_sum(cR, red);
+    tdig_t* dL = dig + (2 * pr) * (size_t)NT * W;
+    tdig_t* dR = dig + (2 * pr + 1) * (size_t)NT * W;
+    for (int t = threadIdx.x; t < nm; t += (int)blockDim.x) {
+        const int r = t & (n - 1);
+        const fqm g = cG[pr * nm + t], hh = cH[pr * nm + t];
+        if (r >= h) {
+            pv_digits(fqm_mul(A[r - h], g), c, W, dL + (size_t)t * W);          // <a_L, G_R>
+            pv_zero(W, dL + (size_t)(nm + t) * W);
+            pv_zero(W, dR + (size_t)t * W);
+            pv_digits(fqm_mul(B[r - h], hh), c, W, dR + (size_t)(nm + t) * W);  // <b_L, H_R>
+        } else {
+            pv_zero(W, dL + (size_t)t * W);
+            pv_digits(fqm_mul(B[h + r], hh), c, W, dL + (size_t)(nm + t) * W);  // <b_R, H_L>
+            pv_digits(fqm_mul(A[h + r], g), c, W, dR + (size_t)t * W);          // <a_R, G_L>
+            pv_zero(W, dR + (size_t)(nm + t) * W);
+        }
+    }
+    if (threadIdx.x == 0) {
+        const fqm xu = pv_be(xu_be + 32 * pr);
+        pv_digits(fqm_mul(cL, xu), c, W, dL + (size_t)(2 * nm) * W);
+        pv_zero(W, dL + (size_t)(2 * nm + 1) * W);
+        pv_digits(fqm_mul(cR, xu), c, W, dR + (size_t)(2 * nm) * W);
+        pv_zero(W, dR + (size_t)(2 * nm + 1) * W);
+    }
+}
+
+// a' = x a_L + x^-1 a_R, b' = x b_R + x^-1 b_L (:122-137); the base folds G' = x^-1 G_L + x G_R, H' = x H_L + x^-1 H_R
+// (:140-155) become updates of the coefficient vectors
+__global__ __launch_bounds__(PV_T) void k_pv_fold(int nm, int n, const uint8_t* __restrict__ xj_be, fqm* __restrict__ a, fqm* __restrict__ b,
+                                                  fqm* __restrict__ cG, fqm* __restrict__ cH) {
+    __shared__ fqm xs[2];
+    const size_t pr = blockIdx.x;
+    const int h = n / 2;
+    if (threadIdx.x == 0) {
+        xs[0] = pv_be(xj_be + 32 * pr);
+        xs[1] = fqm_inv_var(xs[0]);  // (x = 0 is refused by the host before this launch)
+    }
+    __syncthreads();
+    const fqm x = xs[0], xi = xs[1];
+    fqm* A = a + pr * nm;
+    fqm* B = b + pr * nm;
+    for (int i = threadIdx.x; i < h; i += (int)blockDim.x) {  // lane i reads and writes only its own pair of slots
+        const fqm an = fqm_add(fqm_mul(A[i], x), fqm_mul(A[h + i], xi));
+        const fqm bn = fqm_add(fqm_mul(B[h + i], x), fqm_mul(B[i], xi));
+        A[i] = an;
+        B[i] = bn;
+    }
+    if (h != 1)
+        for (int t = threadIdx.x; t < nm; t += (int)blockDim.x) {
+            const bool lower = (t & (n - 1)) < h;
+            cG[pr * nm + t] = fqm_mul(cG[pr * nm + t], lower ? xi : x);
+            cH[pr * nm + t] = fqm_mul(cH[pr * nm + t], lower ? x : xi);
+        }
+}
+
+__global__ void k_pv_final(size_t nproofs, int nm, const fqm* __restrict__ a, const fqm* __restrict__ b, uint8_t* __restrict__ out_be /* [N][64] */) {
+    const size_t pr = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pr >= nproofs) return;
+    fq_to_be(out_be + 64 * pr, fqm_to_fq(a[pr * nm]));
+    fq_to_be(out_be + 64 * pr + 32, fqm_to_fq(b[pr * nm]));
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------------------
+hipError_t launch_pv_init(size_t nproofs, int nm, int c, int W, const uint8_t* tapes, size_t tape_len, const uint8_t* bits, fqm* SL, fqm* SR,
+                          tdig_t* dig, hipStream_t st) {
+    hipLaunchKernelGGL(k_pv_init, dim3((unsigned)nproofs), dim3(pv_lanes(nm)), 0, st, nm, c, W, tapes, tape_len, bits, SL, SR, dig);
+    return hipGetLastError();
+}
+hipError_t launch_pv_term(size_t nproofs, int nm, int c, int W, int row, const uint8_t* scalars_be, tdig_t* dig, hipStream_t st) {
+    hipLaunchKernelGGL(k_pv_term, dim3((unsigned)nproofs), dim3(pv_lanes(nm)), 0, st, nm, c, W, row, scalars_be, dig);
+    return hipGetLastError();
+}
+hipError_t launch_pv_poly(size_t nproofs, int n_bits, int m, int c, int W, const uint8_t* tapes, size_t tape_len, const uint8_t* yz_be,
+                          const uint8_t* bits, const fqm* SL, const fqm* SR, fqm* yi, fqm* zpow, fqm* yinv, tdig_t* dig, hipStream_t st) {
+    hipLaunchKernelGGL(k_pv_poly, dim3((unsigned)nproofs), dim3(pv_lanes(n_bits * m)), 0, st, n_bits, m, c, W, tapes, tape_len, yz_be, bits, SL, SR, yi, zpow, yinv,
+                       dig);
+    return hipGetLastError();
+}
+hipError_t launch_pv_lr(size_t nproofs, int n_bits, int m, const uint8_t* tapes, size_t tape_len, const uint8_t* yz_be, const uint8_t* x_be,
+                        const uint8_t* blindings_be, const uint8_t* bits, const fqm* SL, const fqm* SR, const fqm* yi, const fqm* zpow,
+                        const fqm* yinv, fqm* a, fqm* b, fqm* cG, fqm* cH, uint8_t* out_be, hipStream_t st) {
+    hipLaunchKernelGGL(k_pv_lr, dim3((unsigned)nproofs), dim3(pv_lanes(n_bits * m)), 0, st, n_bits, m, tapes, tape_len, yz_be, x_be, blindings_be, bits, SL, SR, yi,
+                       zpow, yinv, a, b, cG, cH, out_be);
+    return hipGetLastError();
+}
+hipError_t launch_pv_round(size_t nproofs, int nm, int n, int c, int W, const uint8_t* xu_be, const fqm* a, const fqm* b, const fqm* cG,
+                           const fqm* cH, tdig_t* dig, hipStream_t st) {
+    hipLaunchKernelGGL(k_pv_round, dim3((unsigned)nproofs), dim3(pv_lanes(nm)), 0, st, nm, n, c, W, xu_be, a, b, cG, cH, dig);
+    return hipGetLastError();
+}
+hipError_t launch_pv_fold(size_t nproofs, int nm, int n, const uint8_t* xj_be, fqm* a, fqm* b, fqm* cG, fqm* cH, hipStream_t st) {
+    hipLaunchKernelGGL(k_pv_fold, dim3((unsigned)nproofs), dim3(pv_lanes(nm)), 0, st, nm, n, xj_be, a, b, cG, cH);
+    return hipGetLastError();
+}
+hipError_t launch_pv_final(size_t nproofs, int nm, const fqm* a, const fqm* b, uint8_t* out_be, hipStream_t st) {
+    hipLaunchKernelGGL(k_pv_final, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, nproofs, nm, a, b, out_be);
+    return hipGetLastError();
+}
+
+}  // namespace bp
