@@ -1064,12 +1064,12 @@ def main():
 
     plus = c2 = c4 = msm = prove_c1 = None
     if world == 1 and not args.no_prove:
-        prove_c1 = prover_numbers(gens, 0, ("bp_cases.json", 3), 512)  # BASELINE.json configs[0]: n=64 m=1 prove (+ verify)
+        prove_c1 = prover_numbers(gens, 0, ("bp_cases.json", 3), 4096)  # BASELINE.json configs[0]: n=64 m=1 prove (+ verify)
     if world == 1 and not args.no_bpplus:
         plus = side_batch(1, 1, P, "bp_wip_rangeproof_verify_batch_device: RangeProofWIP::aggregated_verify (Bulletproofs+), n=64 m=1")
     if world == 1 and not args.no_c2:
         c2 = side_batch(0, 16, max(256, P // 16), "bp_rangeproof_verify_batch_device at BASELINE.json configs[1]'s shape: "
-                        "RangeProof::aggregated_verify, n=64 m=16", fixture=("bp_c2_n64_m16.json", None), nb=128)
+                        "RangeProof::aggregated_verify, n=64 m=16", fixture=("bp_c2_n64_m16.json", None), nb=512)
     if world == 1 and not args.no_c4:
         c4 = side_batch(1, 64, max(64, P // 64), "bp_wip_rangeproof_verify_batch_device at BASELINE.json configs[3]'s shape: "
                         "RangeProofWIP::aggregated_verify (range_proof_wip.rs:388-609), n=64 m=64", fixture=("bpplus_c4_n64_m64.json", None), nb=32)

@@ -482,7 +482,8 @@ class Context:
         out = ctypes.create_string_buffer(max(nproofs * proof_len, 1))
         st = (ctypes.c_int32 * max(nproofs, 1))()
         _check(fn(self._h, gens._h, n_bits, m, nproofs, bytes(secrets_be), bytes(blindings_be), bytes(tapes), tape_len, out, proof_len, st))
-        return [out.raw[i * proof_len:(i + 1) * proof_len] for i in range(nproofs)]
+        raw = out.raw  # one copy: .raw copies the whole buffer on every access
+        return [raw[i * proof_len:(i + 1) * proof_len] for i in range(nproofs)]
 
     def rangeproof_prove_batch(self, gens, n_bits, m, secrets_be, blindings_be, tapes, tape_len):
         """`RangeProof::prove` for len(secrets_be)//(32 m) proofs (one GPU launch per protocol step for all) -> list of proofs."""

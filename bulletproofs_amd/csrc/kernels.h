@@ -96,20 +96,25 @@ hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, cons
                           int wip = 0, int nm_tab = 0, int pre = 0,  // pre: vartab already holds the slices' window tables
                           hipStream_t helper = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);  // helper: stream for k_bpv_fix
 size_t bpv_msm_fixpart_bytes(size_t nproofs);
-hipError_t launch_bpv_fix_jobs(int nm, size_t njobs, const affine_mem* table, int c, int W, const tdig_t* digF, const int* bad, xyzz* out,
-                               hipStream_t st);
-// prove_kernels.hip: scalar side of the batch prover RangeProof::prove x N (vectors over [proof][i], digits of the table MSMs)
+// prove_kernels.hip: scalar side of the batch prover RangeProof::prove x N (vectors over [proof][i]) and its table MSMs
+struct pv_ent {  // one term of a table MSM: table slot (row W + window) and the signed window digit
+    uint32_t slot;
+    int32_t d;
+};
 hipError_t launch_pv_init(size_t nproofs, int nm, int c, int W, const uint8_t* tapes, size_t tape_len, const uint8_t* bits, fqm* SL, fqm* SR,
-                          tdig_t* dig, hipStream_t st);
-hipError_t launch_pv_term(size_t nproofs, int nm, int c, int W, int row, const uint8_t* scalars_be, tdig_t* dig, hipStream_t st);
+                          pv_ent* ent, size_t stride, hipStream_t st);
+hipError_t launch_pv_term(size_t nproofs, int c, int W, int row, const uint8_t* scalars_be, pv_ent* ent, size_t stride, hipStream_t st);
 hipError_t launch_pv_poly(size_t nproofs, int n_bits, int m, int c, int W, const uint8_t* tapes, size_t tape_len, const uint8_t* yz_be,
-                          const uint8_t* bits, const fqm* SL, const fqm* SR, fqm* yi, fqm* zpow, fqm* yinv, tdig_t* dig, hipStream_t st);
+                          const uint8_t* bits, const fqm* SL, const fqm* SR, fqm* yi, fqm* zpow, fqm* yinv, pv_ent* ent, size_t stride,
+                          hipStream_t st);
 hipError_t launch_pv_lr(size_t nproofs, int n_bits, int m, const uint8_t* tapes, size_t tape_len, const uint8_t* yz_be, const uint8_t* x_be,
                         const uint8_t* blindings_be, const uint8_t* bits, const fqm* SL, const fqm* SR, const fqm* yi, const fqm* zpow,
                         const fqm* yinv, fqm* a, fqm* b, fqm* cG, fqm* cH, uint8_t* out_be, hipStream_t st);
 hipError_t launch_pv_round(size_t nproofs, int nm, int n, int c, int W, const uint8_t* xu_be, const fqm* a, const fqm* b, const fqm* cG,
-                           const fqm* cH, tdig_t* dig, hipStream_t st);
+                           const fqm* cH, pv_ent* ent, size_t stride, hipStream_t st);
 hipError_t launch_pv_fold(size_t nproofs, int nm, int n, const uint8_t* xj_be, fqm* a, fqm* b, fqm* cG, fqm* cH, hipStream_t st);
+hipError_t launch_pv_msm(size_t njobs, const affine_mem* table, int c, const pv_ent* ent, size_t stride, int cnt0, int cnt1, xyzz* out,
+                         hipStream_t st);
 hipError_t launch_pv_final(size_t nproofs, int nm, const fqm* a, const fqm* b, uint8_t* out_be, hipStream_t st);
 // lanes per proof (> 0) when a batch with tp lanes takes the one-launch small-batch MSM (k_bpv_small) and its window tables
 // are built beside the constants kernel (k_bpv_consts_pre); 0 otherwise

@@ -17,8 +17,10 @@
 
 #include <condition_variable>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <utility>
+#include <chrono>
 #include <vector>
 
 #include "../../include/bpmsm.h"
@@ -1682,9 +1684,10 @@ int bp_wipa_verify(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* hi_tag_xy, s
 namespace {
 
 template <class F>
-void parallel_for(size_t n, F fn) {  // the per-proof SHA-256 of a step: a few host threads once the batch is large
-    const size_t nthr = n >= 512 ? 8 : (n >= 128 ? 4 : 1);
-    if (nthr == 1) {
+void parallel_for(size_t n, size_t maxthr, F fn) {  // the per-proof SHA-256 of a step: a few host threads once the batch is large
+    size_t nthr = n / 128;  // >= 128 proofs (~100 us of hashing) per thread
+    if (nthr > maxthr) nthr = maxthr;
+    if (nthr <= 1) {
         for (size_t i = 0; i < n; i++) fn(i);
         return;
     }
@@ -1697,10 +1700,19 @@ void parallel_for(size_t n, F fn) {  // the per-proof SHA-256 of a step: a few h
 }
 
 int prove_batch_device_chunk(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, size_t N, const uint8_t* secrets_be, const uint8_t* blindings_be,
-                             const uint8_t* tapes, size_t tape_len, uint8_t* proofs_out, size_t proof_len, int* st) {
-    const size_t n = (size_t)n_bits, nm = n * (size_t)m, NT = 2 * nm + 2;
+                             const uint8_t* tapes, size_t tape_len, uint8_t* proofs_out, size_t proof_len, int* st, size_t hthreads) {
+    const size_t n = (size_t)n_bits, nm = n * (size_t)m;
     const int k = log2_exact(nm), W = gens->W, c = gens->c;
+    const size_t stride = (2 * nm + 1) * (size_t)W;  // entries of the longest job (S)
     hipStream_t s = ctx->stream;
+    const bool trace = bp_tune("BP_PROVE_TRACE") != nullptr;
+    auto tprev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!trace) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[prove_batch_device] %-10s %8.1f us\n", what, std::chrono::duration<double, std::micro>(now - tprev).count());
+        tprev = now;
+    };
     // device workspace, carved from one buffer
     size_t off = 0;
     auto carve = [&](size_t bytes) {
@@ -1711,8 +1723,7 @@ int prove_batch_device_chunk(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
     const size_t o_tape = carve(N * tape_len), o_bits = carve(N * nm), o_blind = carve(N * (size_t)m * 32), o_SL = carve(N * nm * sizeof(fqm)),
                  o_SR = carve(N * nm * sizeof(fqm)), o_yi = carve(N * nm * sizeof(fqm)), o_a = carve(N * nm * sizeof(fqm)),
                  o_b = carve(N * nm * sizeof(fqm)), o_cG = carve(N * nm * sizeof(fqm)), o_cH = carve(N * nm * sizeof(fqm)),
-                 o_zpow = carve(N * (size_t)m * sizeof(fqm)), o_yinv = carve(N * sizeof(fqm)), o_dig = carve(2 * N * NT * (size_t)W * sizeof(tdig_t)),
-                 o_bad = carve(2 * N * sizeof(int)), o_res = carve(2 * N * sizeof(xyzz)), o_aff = carve(2 * N * sizeof(affine_mem)),
+                 o_zpow = carve(N * (size_t)m * sizeof(fqm)), o_yinv = carve(N * sizeof(fqm)), o_ent = carve(2 * N * stride * sizeof(pv_ent)), o_res = carve(2 * N * sizeof(xyzz)), o_aff = carve(2 * N * sizeof(affine_mem)),
                  o_ptbe = carve(2 * N * 64), o_yz = carve(N * 64), o_x = carve(N * 32), o_xu = carve(N * 32), o_xj = carve(N * 32),
                  o_out = carve(N * 96);
     RC(ctx->proto[0].reserve(off));
@@ -1725,7 +1736,7 @@ int prove_batch_device_chunk(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
     uint8_t* h_bits = h_up + N * 64;          // [N][nm]
     std::vector<uint8_t> ok(N, 1);
     // tape scalars must be canonical and non-zero (Tape::next); the aggregated secret's bits (range_proof.rs:70-91)
-    parallel_for(N, [&](size_t i) {
+    parallel_for(N, hthreads, [&](size_t i) {
         const uint8_t* tp = tapes + i * tape_len;
         for (size_t j = 0; j < 2 * nm + 4; j++) {
             const uint8_t* q = tp + 32 * j;
@@ -1736,16 +1747,16 @@ int prove_batch_device_chunk(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
         std::vector<int> bits = secret_bits(secrets_be + i * (size_t)m * 32, m, n);
         for (size_t j = 0; j < nm; j++) h_bits[i * nm + j] = (uint8_t)bits[j];
     });
+    mark("validate");
     HIPCHK(hipMemcpyAsync(D + o_tape, tapes, N * tape_len, hipMemcpyHostToDevice, s), "h2d tapes");
     HIPCHK(hipMemcpyAsync(D + o_bits, h_bits, N * nm, hipMemcpyHostToDevice, s), "h2d bits");
     HIPCHK(hipMemcpyAsync(D + o_blind, blindings_be, N * (size_t)m * 32, hipMemcpyHostToDevice, s), "h2d blindings");
-    HIPCHK(hipMemsetAsync(D + o_bad, 0, 2 * N * sizeof(int), s), "memset");
     fqm *SL = (fqm*)(D + o_SL), *SR = (fqm*)(D + o_SR), *yi = (fqm*)(D + o_yi), *a = (fqm*)(D + o_a), *b = (fqm*)(D + o_b), *cG = (fqm*)(D + o_cG),
         *cH = (fqm*)(D + o_cH), *zpow = (fqm*)(D + o_zpow), *yinv = (fqm*)(D + o_yinv);
-    tdig_t* dig = (tdig_t*)(D + o_dig);
-    // the table MSMs of one step: njobs dense digit arrays -> affine big-endian points on the host
-    auto msm_step = [&](size_t njobs) -> int {
-        HIPCHK(launch_bpv_fix_jobs((int)nm, njobs, gens->d_table, c, W, dig, (const int*)(D + o_bad), (xyzz*)(D + o_res), s), "table msm");
+    pv_ent* ent = (pv_ent*)(D + o_ent);
+    // the table MSMs of one step: njobs entry lists (cnt0 entries in even jobs, cnt1 in odd ones) -> affine big-endian points on the host
+    auto msm_step = [&](size_t njobs, size_t cnt0, size_t cnt1) -> int {
+        HIPCHK(launch_pv_msm(njobs, gens->d_table, c, ent, stride, (int)cnt0, (int)cnt1, (xyzz*)(D + o_res), s), "table msm");
         HIPCHK(launch_xyzz_to_affine((const xyzz*)(D + o_res), (affine_mem*)(D + o_aff), njobs, s), "normalize");
         HIPCHK(launch_export_points((const affine_mem*)(D + o_aff), D + o_ptbe, njobs, s), "export");
         HIPCHK(hipMemcpyAsync(h_pts, D + o_ptbe, njobs * 64, hipMemcpyDeviceToHost, s), "d2h points");
@@ -1757,10 +1768,11 @@ int prove_batch_device_chunk(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
     std::vector<Fq> y(N), z(N), xu(N);
     std::vector<uint8_t> sc3(N * 96);
     std::vector<std::vector<Pt>> Ls(N, std::vector<Pt>(k)), Rs(N, std::vector<Pt>(k));
+    mark("upload");
     // A, S   (:93-122)
-    HIPCHK(launch_pv_init(N, (int)nm, c, W, D + o_tape, tape_len, D + o_bits, SL, SR, dig, s), "pv_init");
-    RC(msm_step(2 * N));
-    parallel_for(N, [&](size_t i) {
+    HIPCHK(launch_pv_init(N, (int)nm, c, W, D + o_tape, tape_len, D + o_bits, SL, SR, ent, stride, s), "pv_init");
+    RC(msm_step(2 * N, nm + W, stride));
+    parallel_for(N, hthreads, [&](size_t i) {
         memcpy(A[i].b, h_pts + 128 * i, 64);
         memcpy(S[i].b, h_pts + 128 * i + 64, 64);
         if (inf(A[i].b) || inf(S[i].b)) ok[i] = 0;
@@ -1768,28 +1780,31 @@ int prove_batch_device_chunk(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
         if (y[i].is_zero()) ok[i] = 0;
         (ok[i] ? y[i] : Fq(1)).to_be(h_up + 32 * i);
     });
+    mark("A,S");
     // yG = Point::generator() * y, z = H(yG)   (:125-127)
     HIPCHK(hipMemcpyAsync(D + o_x, h_up, N * 32, hipMemcpyHostToDevice, s), "h2d y");
-    HIPCHK(launch_pv_term(N, (int)nm, c, W, gens->ibase, D + o_x, dig, s), "pv_term");
-    RC(msm_step(N));
-    parallel_for(N, [&](size_t i) {
+    HIPCHK(launch_pv_term(N, c, W, gens->ibase, D + o_x, ent, stride, s), "pv_term");
+    RC(msm_step(N, W, W));
+    parallel_for(N, hthreads, [&](size_t i) {
         if (inf(h_pts + 64 * i)) ok[i] = 0;
         z[i] = Transcript().point(h_pts + 64 * i).result_scalar();
         (ok[i] ? y[i] : Fq(1)).to_be(h_up + 64 * i);
         z[i].to_be(h_up + 64 * i + 32);
     });
+    mark("yG");
     // t1, t2, T1, T2   (:131-169)
     HIPCHK(hipMemcpyAsync(D + o_yz, h_up, N * 64, hipMemcpyHostToDevice, s), "h2d yz");
-    HIPCHK(launch_pv_poly(N, n_bits, m, c, W, D + o_tape, tape_len, D + o_yz, D + o_bits, SL, SR, yi, zpow, yinv, dig, s), "pv_poly");
-    RC(msm_step(2 * N));
+    HIPCHK(launch_pv_poly(N, n_bits, m, c, W, D + o_tape, tape_len, D + o_yz, D + o_bits, SL, SR, yi, zpow, yinv, ent, stride, s), "pv_poly");
+    RC(msm_step(2 * N, 2 * W, 2 * W));
     const uint8_t* Gh = &gens->host_be[2 * nm * 64];
     const uint8_t* Hh = &gens->host_be[(2 * nm + 1) * 64];
-    parallel_for(N, [&](size_t i) {
+    parallel_for(N, hthreads, [&](size_t i) {
         memcpy(T1[i].b, h_pts + 128 * i, 64);
         memcpy(T2[i].b, h_pts + 128 * i + 64, 64);
         if (inf(T1[i].b) || inf(T2[i].b)) ok[i] = 0;
         Transcript().point(T1[i].b).point(T2[i].b).point(Gh).point(Hh).result_scalar().to_be(h_up + 32 * i);  // x, :171
     });
+    mark("T1,T2");
     // Lp, Rp, tx, tau_x, miu   (:171-212), then x_u and Gx   (:214-219)
     HIPCHK(hipMemcpyAsync(D + o_x, h_up, N * 32, hipMemcpyHostToDevice, s), "h2d x");
     HIPCHK(launch_pv_lr(N, n_bits, m, D + o_tape, tape_len, D + o_yz, D + o_x, D + o_blind, D + o_bits, SL, SR, yi, zpow, yinv, a, b, cG, cH, D + o_out,
@@ -1797,24 +1812,25 @@ int prove_batch_device_chunk(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
            "pv_lr");
     HIPCHK(hipMemcpyAsync(h_sc, D + o_out, N * 96, hipMemcpyDeviceToHost, s), "d2h scalars");
     HIPCHK(hipStreamSynchronize(s), "sync");
-    parallel_for(N, [&](size_t i) {
+    parallel_for(N, hthreads, [&](size_t i) {
         memcpy(&sc3[96 * i], h_sc + 96 * i, 96);
         xu[i] = Transcript().bigint32(h_sc + 96 * i).bigint32(h_sc + 96 * i + 32).bigint32(h_sc + 96 * i + 64).result_scalar();
         xu[i].to_be(h_up + 32 * i);
     });
     HIPCHK(hipMemcpyAsync(D + o_xu, h_up, N * 32, hipMemcpyHostToDevice, s), "h2d xu");
-    HIPCHK(launch_pv_term(N, (int)nm, c, W, (int)(2 * nm), D + o_xu, dig, s), "pv_term");
-    RC(msm_step(N));
+    HIPCHK(launch_pv_term(N, c, W, (int)(2 * nm), D + o_xu, ent, stride, s), "pv_term");
+    RC(msm_step(N, W, W));
     for (size_t i = 0; i < N; i++) {
         memcpy(ux[i].b, h_pts + 64 * i, 64);
         if (inf(ux[i].b)) ok[i] = 0;
     }
+    mark("lr,Gx");
     // InnerProductArg::prove   (inner_product.rs:36-169)
     size_t len = nm;
     for (int j = 0; j < k; j++, len /= 2) {
-        HIPCHK(launch_pv_round(N, (int)nm, (int)len, c, W, D + o_xu, a, b, cG, cH, dig, s), "pv_round");
-        RC(msm_step(2 * N));
-        parallel_for(N, [&](size_t i) {
+        HIPCHK(launch_pv_round(N, (int)nm, (int)len, c, W, D + o_xu, a, b, cG, cH, ent, stride, s), "pv_round");
+        RC(msm_step(2 * N, (nm + 1) * W, (nm + 1) * W));
+        parallel_for(N, hthreads, [&](size_t i) {
             memcpy(Ls[i][j].b, h_pts + 128 * i, 64);
             memcpy(Rs[i][j].b, h_pts + 128 * i + 64, 64);
             if (inf(Ls[i][j].b) || inf(Rs[i][j].b)) ok[i] = 0;
@@ -1826,10 +1842,11 @@ int prove_batch_device_chunk(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
         HIPCHK(launch_pv_fold(N, (int)nm, (int)len, D + o_xj, a, b, cG, cH, s), "pv_fold");
         if (j + 1 < k) HIPCHK(hipStreamSynchronize(s), "sync");  // h_up is rewritten by the next round
     }
+    mark("rounds");
     HIPCHK(launch_pv_final(N, (int)nm, a, b, D + o_ptbe, s), "pv_final");
     HIPCHK(hipMemcpyAsync(h_pts, D + o_ptbe, N * 64, hipMemcpyDeviceToHost, s), "d2h ab");
     HIPCHK(hipStreamSynchronize(s), "sync");
-    parallel_for(N, [&](size_t i) {
+    parallel_for(N, hthreads, [&](size_t i) {
         if (!ok[i]) {
             st[i] = BP_EINVAL;
             return;
@@ -1844,6 +1861,7 @@ int prove_batch_device_chunk(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
         memcpy(q, h_pts + 64 * i, 64);  // a, b
         st[i] = BP_OK;
     });
+    mark("encode");
     return BP_OK;
 }
 
@@ -1871,20 +1889,64 @@ static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
         return BP_EINVAL;
     }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    // Bulletproofs on the device: the per-proof vectors are kernels over [proof][i] (prove_kernels.hip), the host keeps the
-    // transcript.  (Bulletproofs+ and generators whose G is not the secp256k1 generator keep the host-thread path below.)
-    if (!wip && nm <= 4096 && !bp_tune("BP_PROVE_HOST")) {
-        size_t chunk = ((size_t)1 << 20) / nm;
-        if (chunk > 4096) chunk = 4096;
-        if (chunk < 32) chunk = 32;
-        int first = BP_OK;
-        std::vector<int> stv(nproofs, BP_OK);
-        for (size_t base = 0; base < nproofs; base += chunk) {
-            const size_t cnt = nproofs - base < chunk ? nproofs - base : chunk;
-            int rc = prove_batch_device_chunk(ctx, gens, n_bits, m, cnt, secrets_be + base * (size_t)m * 32, blindings_be + base * (size_t)m * 32,
-                                              tapes + base * tape_len, tape_len, proofs_out + base * proof_len, proof_len, &stv[base]);
+    // Lane l > 0 owns a context of its own (stream, pinned staging, workspaces; created once, kept by `ctx`); lane 0 is `ctx`.
+    auto ensure_lanes = [&](size_t lanes) -> int {
+        while (ctx->prove_lanes.size() + 1 < lanes) {
+            bp_ctx* sub = nullptr;
+            int rc = bp_ctx_create(ctx->device, &sub);
             if (rc != BP_OK) return rc;
+            ctx->prove_lanes.push_back(sub);
         }
+        return BP_OK;
+    };
+    // Bulletproofs on the device: the per-proof vectors are kernels over [proof][i] (prove_kernels.hip), the host keeps the
+    // transcript.  A step of one chunk is launch -> copy back -> hash -> copy up, so the GPU would idle through every host
+    // part: the batch is cut into chunks that run on up to four lanes (host thread + stream each) whose steps overlap.
+    // (Bulletproofs+ keeps the host-thread path below.)
+    if (!wip && nm <= 4096 && !bp_tune("BP_PROVE_HOST")) {
+        size_t lanes = 4;
+        if (const char* e = bp_tune("BP_PROVE_LANES")) lanes = (size_t)atol(e) >= 1 && (size_t)atol(e) <= 8 ? (size_t)atol(e) : lanes;
+        size_t maxchunk = ((size_t)1 << 20) / nm;  // workspace bound: ~0.4 KB of entries per generator term
+        if (maxchunk > 4096) maxchunk = 4096;
+        if (maxchunk < 32) maxchunk = 32;
+        size_t minchunk = ((size_t)1 << 15) / nm;  // below this a step is launch latency only: no point in more lanes
+        if (minchunk < 8) minchunk = 8;
+        size_t chunk = (nproofs + lanes - 1) / lanes;
+        if (chunk < minchunk) chunk = minchunk;
+        if (chunk > maxchunk) chunk = maxchunk;
+        if (const char* e = bp_tune("BP_PROVE_CHUNK")) chunk = (size_t)atol(e) >= 1 && (size_t)atol(e) <= maxchunk ? (size_t)atol(e) : chunk;
+        const size_t nchunks = (nproofs + chunk - 1) / chunk;
+        if (lanes > nchunks) lanes = nchunks;
+        RC(ensure_lanes(lanes));
+        const size_t hthreads = lanes >= 4 ? 2 : (lanes == 2 ? 4 : 8);  // host threads per lane for the per-proof hashing
+        std::vector<int> stv(nproofs, BP_OK), lane_rc(lanes, BP_OK);
+        std::vector<std::string> lane_msg(lanes);  // bp_last_error() is per thread: a lane's text is handed to the caller's
+        auto run_lane = [&](size_t l) {
+            bp_ctx* lctx = l == 0 ? ctx : ctx->prove_lanes[l - 1];
+            if (hipSetDevice(ctx->device) != hipSuccess) {
+                lane_rc[l] = BP_EHIP;
+                return;
+            }
+            for (size_t ci = l; ci < nchunks && lane_rc[l] == BP_OK; ci += lanes) {
+                const size_t base = ci * chunk, cnt = nproofs - base < chunk ? nproofs - base : chunk;
+                lane_rc[l] = prove_batch_device_chunk(lctx, gens, n_bits, m, cnt, secrets_be + base * (size_t)m * 32, blindings_be + base * (size_t)m * 32,
+                                                      tapes + base * tape_len, tape_len, proofs_out + base * proof_len, proof_len, &stv[base], hthreads);
+            }
+            if (lane_rc[l] != BP_OK) lane_msg[l] = bp_last_error();
+        };
+        if (lanes <= 1) {
+            run_lane(0);
+        } else {
+            std::vector<std::thread> thr;
+            for (size_t l = 0; l < lanes; l++) thr.emplace_back(run_lane, l);
+            for (auto& t : thr) t.join();
+        }
+        for (size_t l = 0; l < lanes; l++)
+            if (lane_rc[l] != BP_OK) {
+                set_error_msg(lane_msg[l].c_str());
+                return lane_rc[l];
+            }
+        int first = BP_OK;
         for (size_t i = 0; i < nproofs; i++) {
             if (status) status[i] = stv[i];
             if (stv[i] != BP_OK && first == BP_OK) first = stv[i];
@@ -1904,12 +1966,7 @@ static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
     if (const char* e = bp_tune("BP_PROVE_LANES")) kLanes = (size_t)atol(e) >= 1 && (size_t)atol(e) <= 8 ? (size_t)atol(e) : kLanes;
     const size_t ngroups = (nproofs + kChunk - 1) / kChunk;
     if (kLanes > ngroups) kLanes = ngroups;
-    while (ctx->prove_lanes.size() + 1 < kLanes) {  // lane 0 is `ctx` itself
-        bp_ctx* sub = nullptr;
-        int rc = bp_ctx_create(ctx->device, &sub);
-        if (rc != BP_OK) return rc;
-        ctx->prove_lanes.push_back(sub);
-    }
+    RC(ensure_lanes(kLanes));
     int first_err = BP_OK;
     std::vector<int> st(nproofs, BP_OK);
     auto run_group = [&](bp_ctx* lctx, size_t base) {

@@ -4,9 +4,10 @@
 // Lp / Rp / tx (:186-211), and, per inner-product round, c_L / c_R (:64-65), the folds of a and b (:122-137) and the
 // coefficient vectors that replace the folded bases (G^(j)[i] = sum_{t = i mod n'} cG[t] g_t) - is a kernel
 // over [proof][i] on the reduced-radix Montgomery form `fqm` (fq.h), the way verify_scalars.hip does it for the verifier.
-// The kernels write the window digits of the table MSMs (k_bpv_fix, verify_kernels.hip: dense [job][(2nm+2) W] digit
-// arrays, two jobs per proof) directly; the host keeps only the Fiat-Shamir transcript (SHA-256 of the points each step
-// returns) and the proof encoding.  Same values mod q, same group elements, hence the same proof bytes as the host path
+// The kernels write the terms of the table MSMs directly, as compact lists of (table slot, signed window digit) entries
+// - only the rows a step uses: 77 entries for A, (nm + 1) W for an L or R, W for a one-term job - which k_pv_msm sums (two
+// jobs per proof); the host keeps only the Fiat-Shamir transcript (SHA-256 of the points each step returns) and the
+// proof encoding.  Same values mod q, same group elements, hence the same proof bytes as the host path
 // (tests/test_gpu_proto.py::test_prove_batch_*).
 #include <hip/hip_runtime.h>
 
@@ -19,7 +20,8 @@ namespace bp {
 #define PV_T 256  // most lanes of a per-proof workgroup (strided over i; 64 or 128 for short vectors: pv_lanes)
 static unsigned pv_lanes(int nm) { return nm <= 64 ? 64u : (nm <= 128 ? 128u : (unsigned)PV_T); }
 
-__device__ __forceinline__ void pv_store_digits(const fq& kk, int c, int W, tdig_t* __restrict__ out) {
+// the W signed window digits of scalar kk on table row `row`, as entries (slot = row W + w, digit)
+__device__ __forceinline__ void pv_store_digits(const fq& kk, int c, int W, int row, pv_ent* __restrict__ out) {
     const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
     uint32_t carry = 0;
     for (int w = 0; w < W; w++) {
@@ -32,22 +34,20 @@ __device__ __forceinline__ void pv_store_digits(const fq& kk, int c, int W, tdig
             v = (uint32_t)(two >> sh) & mask;
         }
         v += carry;
+        pv_ent e;
+        e.slot = (uint32_t)(row * W + w);
         if (v > half) {
             carry = 1;
-            out[w] = (tdig_t)((int)v - (int)(1u << c));
+            e.d = (int)v - (int)(1u << c);
         } else {
             carry = 0;
-            out[w] = (tdig_t)v;
+            e.d = (int)v;
         }
+        out[w] = e;
     }
 }
-__device__ __forceinline__ void pv_digits(const fqm& s, int c, int W, tdig_t* __restrict__ out) { pv_store_digits(fqm_to_fq(s), c, W, out); }
-__device__ __forceinline__ void pv_zero(int W, tdig_t* __restrict__ out) {
-    for (int w = 0; w < W; w++) out[w] = 0;
-}
-__device__ __forceinline__ void pv_unit(int W, tdig_t* __restrict__ out, int d) {  // the scalar d = -1, 0 or 1: one digit
-    out[0] = (tdig_t)d;
-    for (int w = 1; w < W; w++) out[w] = 0;
+__device__ __forceinline__ void pv_digits(const fqm& s, int c, int W, int row, pv_ent* __restrict__ out) {
+    pv_store_digits(fqm_to_fq(s), c, W, row, out);
 }
 __device__ __forceinline__ fqm pv_be(const uint8_t* be32) { return fqm_from_fq(fq_from_be_reduce(be32)); }
 __device__ __forceinline__ fqm pv_pow(fqm base, uint32_t e) {
@@ -87,55 +87,48 @@ __device__ __forceinline__ fqm pv_block_sum(fqm v, fqm* red) {
 #define TP_TAU1(nm) (2 + 2 * (nm))
 #define TP_TAU2(nm) (3 + 2 * (nm))
 
-// A = alpha H + sum_{bit} g_i - sum_{!bit} h_i (:93-107) and S = rho H + sum SL_i g_i + SR_i h_i (:116-122): digits of the
-// two jobs of proof pr (jobs 2 pr, 2 pr + 1); SL, SR kept as fqm for the later steps.
+// A = alpha H + sum_{bit} g_i - sum_{!bit} h_i (:93-107) and S = rho H + sum SL_i g_i + SR_i h_i (:116-122): entries of the
+// two jobs of proof pr (jobs 2 pr, 2 pr + 1; nm + W and (2 nm + 1) W entries); SL, SR kept as fqm for the later steps.
 __global__ __launch_bounds__(PV_T) void k_pv_init(int nm, int c, int W, const uint8_t* __restrict__ tapes, size_t tape_len,
                                                   const uint8_t* __restrict__ bits, fqm* __restrict__ SL, fqm* __restrict__ SR,
-                                                  tdig_t* __restrict__ dig) {
+                                                  pv_ent* __restrict__ ent, size_t stride) {
     const size_t pr = blockIdx.x;
-    const int NT = 2 * nm + 2;
     const uint8_t* tp = tapes + pr * tape_len;
-    tdig_t* dA = dig + (2 * pr) * (size_t)NT * W;
-    tdig_t* dS = dig + (2 * pr + 1) * (size_t)NT * W;
+    pv_ent* eA = ent + (2 * pr) * stride;
+    pv_ent* eS = ent + (2 * pr + 1) * stride;
     for (int i = threadIdx.x; i < nm; i += (int)blockDim.x) {
         const fqm sr = pv_be(tp + 32 * (size_t)TP_SR(i)), sl = pv_be(tp + 32 * (size_t)TP_SL(nm, i));
         SR[pr * nm + i] = sr;
         SL[pr * nm + i] = sl;
         const int bit = bits[pr * nm + i];
-        pv_unit(W, dA + (size_t)i * W, bit ? 1 : 0);
-        pv_unit(W, dA + (size_t)(nm + i) * W, bit ? 0 : -1);
-        pv_digits(sl, c, W, dS + (size_t)i * W);
-        pv_digits(sr, c, W, dS + (size_t)(nm + i) * W);
+        pv_ent u;  // + g_i or - h_i: digit +-1 of window 0
+        u.slot = (uint32_t)((bit ? i : nm + i) * W);
+        u.d = bit ? 1 : -1;
+        eA[i] = u;
+        pv_digits(sl, c, W, i, eS + (size_t)i * W);
+        pv_digits(sr, c, W, nm + i, eS + (size_t)(nm + i) * W);
     }
     if (threadIdx.x == 0) {
-        pv_zero(W, dA + (size_t)(2 * nm) * W);
-        pv_zero(W, dS + (size_t)(2 * nm) * W);
-        pv_digits(pv_be(tp + 32 * TP_ALPHA), c, W, dA + (size_t)(2 * nm + 1) * W);
-        pv_digits(pv_be(tp + 32 * TP_RHO), c, W, dS + (size_t)(2 * nm + 1) * W);
+        pv_digits(pv_be(tp + 32 * TP_ALPHA), c, W, 2 * nm + 1, eA + nm);
+        pv_digits(pv_be(tp + 32 * TP_RHO), c, W, 2 * nm + 1, eS + (size_t)(2 * nm) * W);
     }
 }
 
 // one job per proof with ONE term: scalars[pr] times table row `row` (y * generator :126, x_u * G :219)
-__global__ __launch_bounds__(PV_T) void k_pv_term(int nm, int c, int W, int row, const uint8_t* __restrict__ scalars_be, tdig_t* __restrict__ dig) {
-    const size_t pr = blockIdx.x;
-    const int NT = 2 * nm + 2;
-    tdig_t* d = dig + pr * (size_t)NT * W;
-    for (int t = threadIdx.x; t < NT; t += (int)blockDim.x) {
-        if (t == row)
-            pv_digits(pv_be(scalars_be + 32 * pr), c, W, d + (size_t)t * W);
-        else
-            pv_zero(W, d + (size_t)t * W);
-    }
+__global__ void k_pv_term(size_t nproofs, int c, int W, int row, const uint8_t* __restrict__ scalars_be, pv_ent* __restrict__ ent, size_t stride) {
+    const size_t pr = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pr >= nproofs) return;
+    pv_digits(pv_be(scalars_be + 32 * pr), c, W, row, ent + pr * stride);
 }
 
 // yi, z powers, t1, t2 (:131-162) and the digits of T1 = t1 G + tau1 H, T2 = t2 G + tau2 H (:168-169); y^-1 for hi_tag
 __global__ __launch_bounds__(PV_T) void k_pv_poly(int n_bits, int m, int c, int W, const uint8_t* __restrict__ tapes, size_t tape_len,
                                                   const uint8_t* __restrict__ yz_be /* [N][2][32] */, const uint8_t* __restrict__ bits,
                                                   const fqm* __restrict__ SL, const fqm* __restrict__ SR, fqm* __restrict__ yi,
-                                                  fqm* __restrict__ zpow /* [N][m] */, fqm* __restrict__ yinv, tdig_t* __restrict__ dig) {
+                                                  fqm* __restrict__ zpow /* [N][m] */, fqm* __restrict__ yinv, pv_ent* __restrict__ ent, size_t stride) {
     __shared__ fqm red[PV_T];
     const size_t pr = blockIdx.x;
-    const int nm = n_bits * m, NT = 2 * nm + 2;
+    const int nm = n_bits * m;
     const fqm y = pv_be(yz_be + 64 * pr), z = pv_be(yz_be + 64 * pr + 32), ONE = fqm_one();
     fqm t1 = fqm_zero(), t2 = fqm_zero();
     for (int i = threadIdx.x; i < nm; i += (int)blockDim.x) {
@@ -153,18 +146,14 @@ __global__ __launch_bounds__(PV_T) void k_pv_poly(int n_bits, int m, int c, int 
     }
     t1 = pv_block_sum(t1, red);
     t2 = pv_block_sum(t2, red);
-    tdig_t* d1 = dig + (2 * pr) * (size_t)NT * W;
-    tdig_t* d2 = dig + (2 * pr + 1) * (size_t)NT * W;
-    for (int t = threadIdx.x; t < 2 * nm; t += (int)blockDim.x) {
-        pv_zero(W, d1 + (size_t)t * W);
-        pv_zero(W, d2 + (size_t)t * W);
-    }
+    pv_ent* e1 = ent + (2 * pr) * stride;  // 2 W entries each
+    pv_ent* e2 = ent + (2 * pr + 1) * stride;
     if (threadIdx.x == 0) {
         const uint8_t* tp = tapes + pr * tape_len;
-        pv_digits(t1, c, W, d1 + (size_t)(2 * nm) * W);
-        pv_digits(pv_be(tp + 32 * (size_t)TP_TAU1(nm)), c, W, d1 + (size_t)(2 * nm + 1) * W);
-        pv_digits(t2, c, W, d2 + (size_t)(2 * nm) * W);
-        pv_digits(pv_be(tp + 32 * (size_t)TP_TAU2(nm)), c, W, d2 + (size_t)(2 * nm + 1) * W);
+        pv_digits(t1, c, W, 2 * nm, e1);
+        pv_digits(pv_be(tp + 32 * (size_t)TP_TAU1(nm)), c, W, 2 * nm + 1, e1 + W);
+        pv_digits(t2, c, W, 2 * nm, e2);
+        pv_digits(pv_be(tp + 32 * (size_t)TP_TAU2(nm)), c, W, 2 * nm + 1, e2 + W);
         fqm zp = fqm_mul(z, z);
         for (int j = 0; j < m; j++) {
             zpow[pr * m + j] = zp;
@@ -212,14 +201,14 @@ __global__ __launch_bounds__(PV_T) void k_pv_lr(int n_bits, int m, const uint8_t
 }
 
 // One inner-product round over the ORIGINAL generators (n = current length, h = n / 2): c_L, c_R (inner_product.rs:64-65) and
-// the digits of  L = <a_L, G_R> + <b_R, H_L> + c_L ux (:70-90),  R = <a_R, G_L> + <b_L, H_R> + c_R ux (:95-115)  with
+// the entries of  L = <a_L, G_R> + <b_R, H_L> + c_L ux (:70-90),  R = <a_R, G_L> + <b_L, H_R> + c_R ux (:95-115)  with
 // G^(j), H^(j) written through the coefficient vectors cG, cH; ux = xu * G, so its term is the scalar c xu on G's row.
 __global__ __launch_bounds__(PV_T) void k_pv_round(int nm, int n, int c, int W, const uint8_t* __restrict__ xu_be, const fqm* __restrict__ a,
                                                    const fqm* __restrict__ b, const fqm* __restrict__ cG, const fqm* __restrict__ cH,
-                                                   tdig_t* __restrict__ dig) {
+                                                   pv_ent* __restrict__ ent, size_t stride) {
     __shared__ fqm red[PV_T];
     const size_t pr = blockIdx.x;
-    const int h = n / 2, NT = 2 * nm + 2;
+    const int h = n / 2;
     const fqm* A = a + pr * nm;
     const fqm* B = b + pr * nm;
     fqm cL = fqm_zero(), cR = fqm_zero();
@@ -229,29 +218,23 @@ __global__ __launch_bounds__(PV_T) void k_pv_round(int nm, int n, int c, int W, 
     }
     cL = pv_block_sum(cL, red);
     cR = pv_block_sum(cR, red);
-    tdig_t* dL = dig + (2 * pr) * (size_t)NT * W;
-    tdig_t* dR = dig + (2 * pr + 1) * (size_t)NT * W;
+    pv_ent* eL = ent + (2 * pr) * stride;  // (nm + 1) W entries each: term t of a job is its t-th generator row
+    pv_ent* eR = ent + (2 * pr + 1) * stride;
     for (int t = threadIdx.x; t < nm; t += (int)blockDim.x) {
         const int r = t & (n - 1);
         const fqm g = cG[pr * nm + t], hh = cH[pr * nm + t];
         if (r >= h) {
-            pv_digits(fqm_mul(A[r - h], g), c, W, dL + (size_t)t * W);          // <a_L, G_R>
-            pv_zero(W, dL + (size_t)(nm + t) * W);
-            pv_zero(W, dR + (size_t)t * W);
-            pv_digits(fqm_mul(B[r - h], hh), c, W, dR + (size_t)(nm + t) * W);  // <b_L, H_R>
+            pv_digits(fqm_mul(A[r - h], g), c, W, t, eL + (size_t)t * W);            // <a_L, G_R>
+            pv_digits(fqm_mul(B[r - h], hh), c, W, nm + t, eR + (size_t)t * W);      // <b_L, H_R>
         } else {
-            pv_zero(W, dL + (size_t)t * W);
-            pv_digits(fqm_mul(B[h + r], hh), c, W, dL + (size_t)(nm + t) * W);  // <b_R, H_L>
-            pv_digits(fqm_mul(A[h + r], g), c, W, dR + (size_t)t * W);          // <a_R, G_L>
-            pv_zero(W, dR + (size_t)(nm + t) * W);
+            pv_digits(fqm_mul(B[h + r], hh), c, W, nm + t, eL + (size_t)t * W);      // <b_R, H_L>
+            pv_digits(fqm_mul(A[h + r], g), c, W, t, eR + (size_t)t * W);            // <a_R, G_L>
         }
     }
     if (threadIdx.x == 0) {
         const fqm xu = pv_be(xu_be + 32 * pr);
-        pv_digits(fqm_mul(cL, xu), c, W, dL + (size_t)(2 * nm) * W);
-        pv_zero(W, dL + (size_t)(2 * nm + 1) * W);
-        pv_digits(fqm_mul(cR, xu), c, W, dR + (size_t)(2 * nm) * W);
-        pv_zero(W, dR + (size_t)(2 * nm + 1) * W);
+        pv_digits(fqm_mul(cL, xu), c, W, 2 * nm, eL + (size_t)nm * W);
+        pv_digits(fqm_mul(cR, xu), c, W, 2 * nm, eR + (size_t)nm * W);
     }
 }
 
@@ -284,6 +267,62 @@ __global__ __launch_bounds__(PV_T) void k_pv_fold(int nm, int n, const uint8_t* 
         }
 }
 
+// The table MSMs of one step: job j sums its cnt (even jobs: cnt0, odd jobs: cnt1) entries ent[j stride ..], one table
+// gather and one mixed addition per entry (the table of bp_gens: [slot][2^(c-1)] affine multiples), TP lanes per job with
+// the next gather in flight behind the current addition (as bpv_fix_lane_sum, verify_kernels.hip), LDS tree, one XYZZ sum
+// per job.
+template <int TP>
+__global__ __launch_bounds__(256, 3) void k_pv_msm(size_t njobs, const affine_mem* __restrict__ table, int c, const pv_ent* __restrict__ ent,
+                                                   size_t stride, int cnt0, int cnt1, xyzz* __restrict__ out) {
+    __shared__ xyzz red[256];
+    const int tid = threadIdx.x, lane = tid % TP;
+    const size_t job = (size_t)blockIdx.x * (256 / TP) + tid / TP;
+    xyzz acc = xyzz_inf();
+    if (job < njobs) {
+        const int n = (job & 1) ? cnt1 : cnt0;
+        const pv_ent* e = ent + job * stride;
+        const size_t NB = (size_t)1 << (c - 1);
+        auto fetch = [&](int idx) { return e[idx < n ? idx : n - 1]; };
+        auto gather = [&](const pv_ent& t) {
+            const int a = t.d < 0 ? -t.d : t.d;
+            return affine_mem_ld(table + (size_t)t.slot * NB + (a ? a - 1 : 0));
+        };
+        auto add = [&](const affine_mem& m, const pv_ent& t, int idx) {
+            if (t.d != 0 && idx < n) {
+                affine p = affine_load(m);
+                xyzz_madd_s(acc, p, t.d < 0);
+            }
+        };
+        pv_ent tA = fetch(lane), tB = fetch(lane + TP);
+        affine_mem A = gather(tA), B;
+        for (int idx = lane; idx < n; idx += 2 * TP) {
+            pv_ent tN = fetch(idx + 2 * TP);
+            B = gather(tB);
+            add(A, tA, idx);
+            tA = tN;
+            tN = fetch(idx + 3 * TP);
+            A = gather(tA);
+            add(B, tB, idx + TP);
+            tB = tN;
+        }
+    }
+    if (TP > 1) {
+        red[tid] = acc;
+        __syncthreads();
+        for (int off = TP / 2; off >= 1; off >>= 1) {
+            if (lane < off) {
+                xyzz v = red[tid];
+                xyzz o = red[tid + off];
+                xyzz_add(v, o);
+                red[tid] = v;
+            }
+            __syncthreads();
+        }
+        acc = red[tid];
+    }
+    if (lane == 0 && job < njobs) out[job] = acc;
+}
+
 __global__ void k_pv_final(size_t nproofs, int nm, const fqm* __restrict__ a, const fqm* __restrict__ b, uint8_t* __restrict__ out_be /* [N][64] */) {
     const size_t pr = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pr >= nproofs) return;
@@ -293,18 +332,19 @@ __global__ void k_pv_final(size_t nproofs, int nm, const fqm* __restrict__ a, co
 
 // ---- launchers -----------------------------------------------------------------------------------------------------
 hipError_t launch_pv_init(size_t nproofs, int nm, int c, int W, const uint8_t* tapes, size_t tape_len, const uint8_t* bits, fqm* SL, fqm* SR,
-                          tdig_t* dig, hipStream_t st) {
-    hipLaunchKernelGGL(k_pv_init, dim3((unsigned)nproofs), dim3(pv_lanes(nm)), 0, st, nm, c, W, tapes, tape_len, bits, SL, SR, dig);
+                          pv_ent* ent, size_t stride, hipStream_t st) {
+    hipLaunchKernelGGL(k_pv_init, dim3((unsigned)nproofs), dim3(pv_lanes(nm)), 0, st, nm, c, W, tapes, tape_len, bits, SL, SR, ent, stride);
     return hipGetLastError();
 }
-hipError_t launch_pv_term(size_t nproofs, int nm, int c, int W, int row, const uint8_t* scalars_be, tdig_t* dig, hipStream_t st) {
-    hipLaunchKernelGGL(k_pv_term, dim3((unsigned)nproofs), dim3(pv_lanes(nm)), 0, st, nm, c, W, row, scalars_be, dig);
+hipError_t launch_pv_term(size_t nproofs, int c, int W, int row, const uint8_t* scalars_be, pv_ent* ent, size_t stride, hipStream_t st) {
+    hipLaunchKernelGGL(k_pv_term, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, nproofs, c, W, row, scalars_be, ent, stride);
     return hipGetLastError();
 }
 hipError_t launch_pv_poly(size_t nproofs, int n_bits, int m, int c, int W, const uint8_t* tapes, size_t tape_len, const uint8_t* yz_be,
-                          const uint8_t* bits, const fqm* SL, const fqm* SR, fqm* yi, fqm* zpow, fqm* yinv, tdig_t* dig, hipStream_t st) {
+                          const uint8_t* bits, const fqm* SL, const fqm* SR, fqm* yi, fqm* zpow, fqm* yinv, pv_ent* ent, size_t stride,
+                          hipStream_t st) {
     hipLaunchKernelGGL(k_pv_poly, dim3((unsigned)nproofs), dim3(pv_lanes(n_bits * m)), 0, st, n_bits, m, c, W, tapes, tape_len, yz_be, bits, SL, SR, yi, zpow, yinv,
-                       dig);
+                       ent, stride);
     return hipGetLastError();
 }
 hipError_t launch_pv_lr(size_t nproofs, int n_bits, int m, const uint8_t* tapes, size_t tape_len, const uint8_t* yz_be, const uint8_t* x_be,
@@ -315,8 +355,30 @@ hipError_t launch_pv_lr(size_t nproofs, int n_bits, int m, const uint8_t* tapes,
     return hipGetLastError();
 }
 hipError_t launch_pv_round(size_t nproofs, int nm, int n, int c, int W, const uint8_t* xu_be, const fqm* a, const fqm* b, const fqm* cG,
-                           const fqm* cH, tdig_t* dig, hipStream_t st) {
-    hipLaunchKernelGGL(k_pv_round, dim3((unsigned)nproofs), dim3(pv_lanes(nm)), 0, st, nm, n, c, W, xu_be, a, b, cG, cH, dig);
+                           const fqm* cH, pv_ent* ent, size_t stride, hipStream_t st) {
+    hipLaunchKernelGGL(k_pv_round, dim3((unsigned)nproofs), dim3(pv_lanes(nm)), 0, st, nm, n, c, W, xu_be, a, b, cG, cH, ent, stride);
+    return hipGetLastError();
+}
+// njobs jobs of cnt0 (even) / cnt1 (odd) entries; lanes per job so that the launch has about four waves per SIMD
+hipError_t launch_pv_msm(size_t njobs, const affine_mem* table, int c, const pv_ent* ent, size_t stride, int cnt0, int cnt1, xyzz* out,
+                         hipStream_t st) {
+    if (njobs == 0) return hipSuccess;
+    if (cnt0 < 1 || cnt1 < 1 || (size_t)cnt0 > stride || (size_t)cnt1 > stride) return hipErrorInvalidValue;
+    int tp = 64;
+    while (tp > 4 && (njobs * (size_t)tp > ((size_t)1 << 18) || tp * 4 > (cnt0 > cnt1 ? cnt0 : cnt1))) tp >>= 1;
+    const unsigned blocks = (unsigned)((njobs + (256 / tp) - 1) / (256 / tp));
+#define PV_MSM(TP) hipLaunchKernelGGL((k_pv_msm<TP>), dim3(blocks), dim3(256), 0, st, njobs, table, c, ent, stride, cnt0, cnt1, out)
+    if (tp == 64)
+        PV_MSM(64);
+    else if (tp == 32)
+        PV_MSM(32);
+    else if (tp == 16)
+        PV_MSM(16);
+    else if (tp == 8)
+        PV_MSM(8);
+    else
+        PV_MSM(4);
+#undef PV_MSM
     return hipGetLastError();
 }
 hipError_t launch_pv_fold(size_t nproofs, int nm, int n, const uint8_t* xj_be, fqm* a, fqm* b, fqm* cG, fqm* cH, hipStream_t st) {

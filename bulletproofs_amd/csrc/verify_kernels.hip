@@ -436,27 +436,6 @@ int bpv_small_fused(int tp) {
     static const bool split = bp_tune("BP_VERIFY_SMALL_SPLIT") != nullptr;  // A/B: the two-launch form
     return (tp < 0 && -tp <= 128 && !split) ? -tp : 0;
 }
-// k_bpv_fix on its own: njobs dense digit arrays [(2nm+2) W] -> one XYZZ sum each (the batch prover's table MSMs, prove_kernels.hip)
-hipError_t launch_bpv_fix_jobs(int nm, size_t njobs, const affine_mem* table, int c, int W, const tdig_t* digF, const int* bad, xyzz* out,
-                               hipStream_t st) {
-    if (njobs == 0) return hipSuccess;
-    const int tf = njobs <= 4096 ? 64 : (njobs <= 8192 ? 32 : (njobs <= 16384 ? 16 : (njobs <= 32768 ? 8 : 4)));
-    const unsigned fblocks = (unsigned)((njobs + (256 / tf) - 1) / (256 / tf));
-#define BPV_FIXJ(TP) hipLaunchKernelGGL((k_bpv_fix<TP>), dim3(fblocks), dim3(256), 0, st, nm, njobs, table, c, W, digF, bad, 0, out)
-    if (tf == 64)
-        BPV_FIXJ(64);
-    else if (tf == 32)
-        BPV_FIXJ(32);
-    else if (tf == 16)
-        BPV_FIXJ(16);
-    else if (tf == 8)
-        BPV_FIXJ(8);
-    else
-        BPV_FIXJ(4);
-#undef BPV_FIXJ
-    return hipGetLastError();
-}
-
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
                           const tdig_t* digF, const fq* varS, xyzz* vartab, xyzz* fixpart, const int* bad, uint8_t* verdicts, hipStream_t st,
                           int wip, int nm_tab, int pre, hipStream_t helper, hipEvent_t ev_fork, hipEvent_t ev_join) {

@@ -233,6 +233,36 @@ def test_prove_batch_matches_single_proofs(ctx, kind, n, m, count):
         gens.close()
 
 
+def test_prove_batch_with_caller_G_and_one_bad_tape(ctx, oracle_c):
+    """The device batch prover with G != Point::generator() (y*G uses the table's extra generator row, x_u*G the caller's G)
+    and one proof of the batch with a zero tape scalar: that proof reports BP_EINVAL, the others are byte-identical to the
+    single-proof call."""
+    n, m, count = 16, 2, 9
+    g, h, _, H = bpa.generate_bases(0, bpa.KZEN_SEED, n, m)
+    G = ec.enc64(oracle_c.mul(ec.G, 0xC0FFEE1234567))
+    gens = bpa.Gens(ctx, g, h, G, H, 6)
+    try:
+        from oracle import tape
+        ntape = 2 + 2 * n * m + 2
+        secs, blinds, tapes = b"", b"", b""
+        for i in range(count):
+            tb = tape.make_tape_bytes("pbG-%d" % i, m + ntape)
+            secs += b"".join(((i * 977 + j) % (1 << n)).to_bytes(32, "big") for j in range(m))
+            blinds += tb[:32 * m]
+            tapes += tb[32 * m:]
+        batch = ctx.rangeproof_prove_batch(gens, n, m, secs, blinds, tapes, 32 * ntape)
+        for i in range(count):
+            want = ctx.rangeproof_prove(gens, n, secs[64 * i:64 * i + 64], blinds[64 * i:64 * i + 64], tapes[32 * ntape * i:32 * ntape * (i + 1)])
+            assert batch[i] == want, i
+        bad = bytearray(tapes)
+        bad[32 * ntape * 4 + 32 * 7:32 * ntape * 4 + 32 * 8] = b"\0" * 32
+        with pytest.raises(bpa.BpError) as e:
+            ctx.rangeproof_prove_batch(gens, n, m, secs, blinds, bytes(bad), 32 * ntape)
+        assert e.value.code == -1
+    finally:
+        gens.close()
+
+
 def test_prove_batch_reports_bad_inputs(ctx):
     g, h, G, H = bpa.generate_bases(0, bpa.KZEN_SEED, 8, 1)
     gens = bpa.Gens(ctx, g, h, G, H, 4)
