@@ -79,20 +79,23 @@ BP_HD xyzz ec_mul_glv(const affine& P, const fq& k, xyzz* tab) {
     return acc;
 }
 
-// One quarter of k * P for latency-bound callers (few points, every lane of the wave free): slice = half + 2 * part,
-// half selects the GLV component (k1 on P, k2 on lambda P), part the window range (0: windows 0..16, 1: windows 17..32 on
-// the base 2^68 * P_half).  The four slices of a point run in four lanes and are summed by the caller's lane tree:
-// the longest lane does 68 + 60 doublings and 16 additions instead of 128 doublings and 66 additions.
-#define ECMUL_SPLIT_W 17
-// The part of a slice that does not depend on the scalar: tab[i] = (i + 1) * base, base = 2^(4 w_lo) * P_half (68 doublings
-// for part 1).  The batch verifier builds these tables beside its scalar kernels (k_bpv_consts_pre), so that only
-// ec_slice_ladder is left once the scalars exist.  P must not be the point at infinity.
-BP_HD void ec_slice_table(const affine& P, int slice, xyzz* tab) {
+// One slice of k * P for latency-bound callers (few points, every lane of the wave free): slice = half + 2 * part,
+// half selects the GLV component (k1 on P, k2 on lambda P), part one of `nparts` window ranges (part p: windows
+// ec_part_lo(p) .. ec_part_lo(p + 1) - 1 on the base 2^(4 ec_part_lo(p)) * P_half).  The 2 nparts slices of a point run in
+// as many lanes and are summed by the caller's lane tree.  nparts = 2 (windows 0..16 | 17..32): the longest lane does 68 +
+// 60 doublings and 16 additions instead of 128 doublings and 66 additions.  The doublings on the critical path stay 128
+// whatever nparts is (a part's base is that many doublings away); more parts move them from the ladder, which needs the
+// scalar, into the table, which does not - nparts = 4: 100 doublings for the last table, 32 + 9 additions per ladder.
+BP_HD int ec_part_lo(int part, int nparts) { return (part * ECMUL_WINS + nparts - 1) / nparts; }  // (2 parts: 0, 17, 33)
+// The part of a slice that does not depend on the scalar: tab[i] = (i + 1) * base, base = 2^(4 w_lo) * P_half.  The batch
+// verifier builds these tables beside its scalar kernels (k_bpv_chain), so that only ec_slice_ladder is left once the
+// scalars exist.  P must not be the point at infinity.
+BP_HD void ec_slice_table(const affine& P, int slice, xyzz* tab, int nparts = 2) {
     const int half = slice & 1, part = slice >> 1;
     affine Ph = P;
     if (half) Ph.x = fp_mul(P.x, fp_beta());
     xyzz base = xyzz_from_affine(Ph);
-    if (part) base = xyzz_dbl_n(base, 4 * ECMUL_SPLIT_W);
+    if (part) base = xyzz_dbl_n(base, 4 * ec_part_lo(part, nparts));
     tab[0] = base;
     xyzz t = xyzz_dbl(base);
     tab[1] = t;
@@ -101,15 +104,15 @@ BP_HD void ec_slice_table(const affine& P, int slice, xyzz* tab) {
         tab[i] = t;
     }
 }
-// the slice's windows over a table made by ec_slice_table for the same (point, slice)
-BP_HD xyzz ec_slice_ladder(const fq& k, int slice, const xyzz* tab) {
+// the slice's windows over a table made by ec_slice_table for the same (point, slice, nparts)
+BP_HD xyzz ec_slice_ladder(const fq& k, int slice, const xyzz* tab, int nparts = 2) {
     fq k1, k2;
     bool n1, n2;
     fq_glv_split(k, k1, n1, k2, n2);
     const int half = slice & 1, part = slice >> 1;
     const fq kk = half ? k2 : k1;
     const bool neg = half ? n2 : n1;
-    const int w_lo = part ? ECMUL_SPLIT_W : 0, w_hi = part ? ECMUL_WINS : ECMUL_SPLIT_W;
+    const int w_lo = ec_part_lo(part, nparts), w_hi = ec_part_lo(part + 1, nparts);
     const uint64_t cm = ecmul_carry_mask(kk);
     xyzz acc = xyzz_inf();
     for (int w = w_hi - 1; w >= w_lo; w--) {
@@ -123,10 +126,10 @@ BP_HD xyzz ec_slice_ladder(const fq& k, int slice, const xyzz* tab) {
     }
     return acc;
 }
-BP_HD xyzz ec_mul_glv_slice(const affine& P, const fq& k, int slice, xyzz* tab) {
+BP_HD xyzz ec_mul_glv_slice(const affine& P, const fq& k, int slice, xyzz* tab, int nparts = 2) {
     if (affine_is_inf(P)) return xyzz_inf();
-    ec_slice_table(P, slice, tab);
-    return ec_slice_ladder(k, slice, tab);
+    ec_slice_table(P, slice, tab, nparts);
+    return ec_slice_ladder(k, slice, tab, nparts);
 }
 
 // Interleaved (Straus) form for several points in ONE lane: sum_j k_j * P_j with a single chain of

@@ -84,7 +84,7 @@ size_t bpv_cst_count(int k, int m);
 hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
                                       const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fqm* scF, fq* varS, fq* chal,
                                       fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st, int ibase, int nm_tab,
-                                      xyzz* pretab = nullptr, int lpp = 0);  // pretab/lpp: small-batch window tables (bpv_small_fused)
+                                      xyzz* pretab = nullptr, int lpp = 0, int nparts = 2);  // pretab/lpp/nparts: small-batch window tables (bpv_small_fused, bpv_small_parts)
 // rlc_kernels.hip: random-linear-combination batch verification (one MSM for the whole batch)
 hipError_t launch_rlc_weights(const uint8_t* seed32, size_t nproofs, const int* bad, fqm* rho, hipStream_t st);
 hipError_t launch_rlc_var_scalars(int k, int m, size_t nproofs, const fqm* rho, const fq* varS, uint8_t* sc_be, hipStream_t st, int wip = 0);
@@ -119,15 +119,16 @@ hipError_t launch_pv_final(size_t nproofs, int nm, const fqm* a, const fqm* b, u
 // lanes per proof (> 0) when a batch with tp lanes takes the one-launch small-batch MSM (k_bpv_small) and its window tables
 // are built beside the constants kernel (k_bpv_consts_pre); 0 otherwise
 int bpv_small_fused(int tp);
+int bpv_small_parts(int tp, int nv);  // window ranges per GLV half of the fused small-batch kernels (0: not fused)
 // Bulletproofs+ twins (RangeProofWIP::aggregated_verify): proof-point order b_tag, A, L[k], R[k], a_tag, V[m]
 hipError_t launch_wipv_decompress(const uint8_t* proofs, size_t proof_len, const uint8_t* coms_xy, int k, int m, size_t nproofs, affine_mem* pts,
                                   int* bad, hipStream_t st);
 hipError_t launch_wipv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
                                        const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fqm* scF, fq* varS, fq* chal,
                                        fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st, int ibase, int nm_tab,
-                                       xyzz* pretab = nullptr, int lpp = 0);
+                                       xyzz* pretab = nullptr, int lpp = 0, int nparts = 2);
 size_t bpv_msm_vartab_bytes(int tp, size_t nproofs);
-int bpv_slice_lanes(int nv);
+int bpv_slice_lanes(int nv, int nparts = 2);
 
 
 // msm_batch.hip

@@ -309,9 +309,16 @@ static VerifySizes verify_ws_sizes(const bp_ctx* ctx, const bp_gens* gens, int n
     // (k_bpv_msm_slice, tp < 0 = minus its lanes per proof; measured on n=64 m=1: 512 proofs 1.21 -> 0.93 ms, 1024 proofs
     // 1.20 -> 0.95 ms, 2048 proofs 1.34 -> 1.55 ms, hence the 65536-lane limit).  bp_verify_set_lanes(ctx, -4) forces that
     // kernel; allow_slice = false keeps the smaller workspace of the ladder kernel (no-allocation entry point).
+    // Eight lanes per point (four window ranges per GLV half) while the batch leaves three quarters of the SIMDs without a wave:
+    // 36 of the ladder's 64 doublings move into the scalar-independent window tables, which are built beside the scalar chain
+    // (k_bpv_chain).  Measured on n=64 m=1, one call alone / two in flight (scripts/experiments/slice8_test.py): 128 proofs
+    // 0.82 / 0.41 -> 0.69 / 0.39 ms, 256 proofs 0.79 / 0.41 -> 0.65 / 0.53, 512 proofs 0.82 / 0.65 -> 1.13 / 0.86 (every SIMD
+    // already has its wave at four lanes per point), hence the 16384-lane limit.  bp_verify_set_lanes(ctx, -8) forces it.
     int tp = ctx->verify_lanes;
-    const int slice_lpp = bpv_slice_lanes(NV);
-    if (allow_slice && (tp == -4 || (tp == 0 && nproofs * (size_t)slice_lpp <= 65536))) {
+    const int slice_lpp = bpv_slice_lanes(NV), slice_lpp8 = bpv_slice_lanes(NV, 4);
+    if (allow_slice && slice_lpp8 <= 128 && (tp == -8 || (tp == 0 && nproofs * (size_t)slice_lpp8 <= 16384))) {
+        tp = -slice_lpp8;
+    } else if (allow_slice && (tp == -4 || tp == -8 || (tp == 0 && nproofs * (size_t)slice_lpp <= 65536))) {
         tp = -slice_lpp;
     } else if (tp != 2 && tp != 4 && tp != 8 && tp != 16 && tp != 32 && tp != 64) {
         // (re-tuned with two calls in flight and the one-call-alone helper stream: profiles/r02_small_batch.txt E)
@@ -427,20 +434,20 @@ static int verify_batch_launch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int
                "bpv_decompress");
     prof_mark(ctx, 1);
     // small batches: the ladders' scalar-independent window tables are built in the constants kernel's launch (into vartab)
-    const int lpp = bpv_small_fused(tp);
+    const int lpp = bpv_small_fused(tp), nparts = bpv_small_parts(tp, (wip ? 2 : 3) + 2 * k + m);
     if (wip)
         HIPCHK(launch_wipv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, ws.pts, gens->d_pts, gens->d_table, gens->c,
                                            gens->W, ws.dig, nullptr, ws.var, d_chal, d_cst, d_fixres, d_fixaff, ws.bad, st, gens->ibase, (int)gens->nm,
-                                           lpp ? ws.vartab : nullptr, lpp),
+                                           lpp ? ws.vartab : nullptr, lpp, nparts ? nparts : 2),
                "wipv_scalars");
     else
         HIPCHK(launch_bpv_scalar_pipeline((const uint8_t*)d_proofs, proof_len, n_bits, m, k, nproofs, ws.pts, gens->d_pts, gens->d_table, gens->c,
                                           gens->W, ws.dig, nullptr, ws.var, d_chal, d_cst, d_fixres, d_fixaff, ws.bad, st, gens->ibase, (int)gens->nm,
-                                          lpp ? ws.vartab : nullptr, lpp),
+                                          lpp ? ws.vartab : nullptr, lpp, nparts ? nparts : 2),
                "bpv_scalars");
     prof_mark(ctx, 2);
     HIPCHK(launch_bpv_msm(tp, n_bits, m, k, nproofs, ws.pts, gens->d_table, gens->c, gens->W, ws.dig, ws.var, ws.vartab, ws.fixpart, ws.bad,
-                          (uint8_t*)d_verdicts, st, wip, (int)gens->nm, lpp ? 1 : 0, use_helper ? ctx->vside : nullptr, ctx->v_ev_fork,
+                          (uint8_t*)d_verdicts, st, wip, (int)gens->nm, nparts, use_helper ? ctx->vside : nullptr, ctx->v_ev_fork,
                           ctx->v_ev_join),
            "bpv_msm");
     prof_mark(ctx, 3);

@@ -352,13 +352,14 @@ __global__ __launch_bounds__(256) void k_bpv_small(int nm, int m, int k, size_t 
             const affine_mem* P = pts + pr * NPT;
             const fq* vs = varS + pr * (size_t)NV;
             xyzz* tab = vartab + (pr * LPP + lane) * ECMUL_NT;
-            for (int idx = lane; idx < 4 * NV; idx += LPP) {
-                const int v = idx >> 2, slice = idx & 3;
+            const int nparts = pre ? pre : 2, nsl = 2 * nparts;  // slices per point (pre: the window ranges the tables were built for)
+            for (int idx = lane; idx < nsl * NV; idx += LPP) {
+                const int v = idx / nsl, slice = idx % nsl;
                 // variable point order: S, L_0.., R_0.., V_0.., T1, T2  ->  index into pts (as in k_bpv_msm)
                 const int pi = wip ? 1 + v : (v == 0) ? 1 : (v < 1 + 2 * k + m) ? (3 + v) : (v == 1 + 2 * k + m ? 2 : 3);
                 // pre: the slice's window table was built beside the constants kernel (k_bpv_consts_pre, verify_scalars.hip)
                 const affine Pv = affine_load(P[pi]);
-                xyzz t = !pre ? ec_mul_glv_slice(Pv, vs[v], slice, tab) : affine_is_inf(Pv) ? xyzz_inf() : ec_slice_ladder(vs[v], slice, tab);
+                xyzz t = !pre ? ec_mul_glv_slice(Pv, vs[v], slice, tab) : affine_is_inf(Pv) ? xyzz_inf() : ec_slice_ladder(vs[v], slice, tab, nparts);
                 xyzz_add(acc, t);
             }
         }
@@ -405,9 +406,9 @@ hipError_t launch_wipv_decompress(const uint8_t* proofs, size_t proof_len, const
 // lanes per proof -> proof-specific points per lane and pass
 static int bpv_ppl(int tp) { return tp == 2 ? 8 : (tp == 4 ? 4 : (tp == 8 ? 2 : 1)); }
 // lanes per proof of the four-lanes-per-point kernel for NV proof-specific points (a power of two, at most one workgroup)
-int bpv_slice_lanes(int nv) {
+int bpv_slice_lanes(int nv, int nparts) {
     int lpp = 16;
-    while (lpp < 4 * nv && lpp < 256) lpp *= 2;
+    while (lpp < 2 * nparts * nv && lpp < 256) lpp *= 2;
     return lpp;
 }
 // tp > 0: lanes per proof of k_bpv_msm; tp < 0: k_bpv_msm_slice with -tp lanes per proof
@@ -435,6 +436,12 @@ static int bpv_fix_lanes(int tp, size_t nproofs, int nm) {
 int bpv_small_fused(int tp) {
     static const bool split = bp_tune("BP_VERIFY_SMALL_SPLIT") != nullptr;  // A/B: the two-launch form
     return (tp < 0 && -tp <= 128 && !split) ? -tp : 0;
+}
+// window ranges per GLV half in the fused small-batch kernels: four when the lanes per proof cover eight slices per point
+// (a power of two >= 4 nv is always < 8 nv, so the lane count alone tells), else two
+int bpv_small_parts(int tp, int nv) {
+    const int lpp = bpv_small_fused(tp);
+    return !lpp ? 0 : (lpp >= 8 * nv ? 4 : 2);
 }
 hipError_t launch_bpv_msm(int tp, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts, const affine_mem* table, int c, int W,
                           const tdig_t* digF, const fq* varS, xyzz* vartab, xyzz* fixpart, const int* bad, uint8_t* verdicts, hipStream_t st,

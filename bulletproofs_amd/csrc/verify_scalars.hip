@@ -143,16 +143,9 @@ __device__ __forceinline__ fq msg_result_scalar(uint8_t* buf, int len) {
 #define CH_COUNT(k) (5 + (k))
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_bpv_hash1(const uint8_t* __restrict__ proofs, size_t proof_len, int k, int m, int nm, size_t nproofs,
-                                                  const affine_mem* __restrict__ pts, const affine_mem* __restrict__ gens, fq* __restrict__ chal,
-                                                  int* __restrict__ bad) {
-    __shared__ __align__(4) uint8_t lds[64 * MSG_STRIDE];
-    size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (gid >= nproofs * 4) return;
-    size_t pr = gid >> 2;
-    int job = (int)(gid & 3);
-    if (bad[pr]) return;
-    uint8_t* buf = lds + threadIdx.x * MSG_STRIDE;
+// one of the four transcript hashes of proof pr (job 0..3) -> chal[pr][job]; a non-canonical proof scalar raises *badflag
+__device__ __forceinline__ void bpv_hash1_job(size_t pr, int job, uint8_t* buf, const uint8_t* __restrict__ proofs, size_t proof_len, int k, int m,
+                                              int nm, const affine_mem* __restrict__ pts, const affine_mem* __restrict__ gens, fq* chal, int* badflag) {
     const int NPT = 4 + 2 * k + m;
     const affine_mem* P = pts + pr * NPT;
     const uint8_t* pf = proofs + pr * proof_len;
@@ -171,7 +164,7 @@ __global__ __launch_bounds__(64) void k_bpv_hash1(const uint8_t* __restrict__ pr
         // scalars in the proof must be canonical (< q), as curv's deserialisation yields
         bool okc = fq_be_is_canonical(sc) && fq_be_is_canonical(sc + 32) && fq_be_is_canonical(sc + 64) && fq_be_is_canonical(ab) &&
                    fq_be_is_canonical(ab + 32);
-        if (!okc) atomicOr(&bad[pr], 1);
+        if (!okc) atomicOr(badflag, 1);
         msg_put_bigint32(buf, pos, sc);
         msg_put_bigint32(buf, pos, sc + 32);
         msg_put_bigint32(buf, pos, sc + 64);
@@ -184,6 +177,16 @@ __global__ __launch_bounds__(64) void k_bpv_hash1(const uint8_t* __restrict__ pr
         msg_put_point(buf, pos, gens[2 * nm + 1]);
     }
     chal[pr * CH_COUNT(k) + job] = msg_result_scalar(buf, pos);
+}
+__global__ __launch_bounds__(64) void k_bpv_hash1(const uint8_t* __restrict__ proofs, size_t proof_len, int k, int m, int nm, size_t nproofs,
+                                                  const affine_mem* __restrict__ pts, const affine_mem* __restrict__ gens, fq* __restrict__ chal,
+                                                  int* __restrict__ bad) {
+    __shared__ __align__(4) uint8_t lds[64 * MSG_STRIDE];
+    size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (gid >= nproofs * 4) return;
+    size_t pr = gid >> 2;
+    if (bad[pr]) return;
+    bpv_hash1_job(pr, (int)(gid & 3), lds + threadIdx.x * MSG_STRIDE, proofs, proof_len, k, m, nm, pts, gens, chal, &bad[pr]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -254,39 +257,31 @@ __global__ __launch_bounds__(256) void k_bpv_fixmul(int k, int nm, size_t nproof
 
 // affine yG, ux with ONE inversion (Montgomery's trick on the two ZZZ).  y = 0 or x_u = 0 makes a
 // result the identity: the reference would panic (:569 mod_inv unwrap) / cannot hash it -> malformed.
-__global__ __launch_bounds__(64) void k_bpv_fixinv(size_t nproofs, const xyzz* __restrict__ fixres, affine_mem* __restrict__ fixaff,
-                                                   int* __restrict__ bad) {
-    size_t pr = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (pr >= nproofs || bad[pr]) return;
-    xyzz a = fixres[pr * 2], b = fixres[pr * 2 + 1];
-    if (xyzz_is_inf(a) || xyzz_is_inf(b)) {
-        atomicOr(&bad[pr], 1);
-        return;
-    }
+__device__ __forceinline__ bool bpv_fixinv_body(const xyzz& a, const xyzz& b, affine_mem* out2) {
+    if (xyzz_is_inf(a) || xyzz_is_inf(b)) return false;
     fp inv = fp_inv_var(fp_mul(a.ZZZ, b.ZZZ));
     fp ia = fp_mul(inv, b.ZZZ), ib = fp_mul(inv, a.ZZZ);
     affine r;
     fp zi = fp_mul(a.ZZ, ia);
     r.x = fp_mul(a.X, fp_sqr(zi));
     r.y = fp_mul(a.Y, ia);
-    fixaff[pr * 2] = affine_store(r);
+    out2[0] = affine_store(r);
     zi = fp_mul(b.ZZ, ib);
     r.x = fp_mul(b.X, fp_sqr(zi));
     r.y = fp_mul(b.Y, ib);
-    fixaff[pr * 2 + 1] = affine_store(r);
+    out2[1] = affine_store(r);
+    return true;
+}
+__global__ __launch_bounds__(64) void k_bpv_fixinv(size_t nproofs, const xyzz* __restrict__ fixres, affine_mem* __restrict__ fixaff,
+                                                   int* __restrict__ bad) {
+    size_t pr = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (pr >= nproofs || bad[pr]) return;
+    if (!bpv_fixinv_body(fixres[pr * 2], fixres[pr * 2 + 1], fixaff + pr * 2)) atomicOr(&bad[pr], 1);
 }
 
 // z = H(yG) (job 0) and x_j = H(L_j, R_j, ux) (job 1 + j)
-__global__ __launch_bounds__(64) void k_bpv_hash2(int k, int m, size_t nproofs, const affine_mem* __restrict__ pts,
-                                                  const affine_mem* __restrict__ fixaff, fq* __restrict__ chal, const int* __restrict__ bad) {
-    __shared__ __align__(4) uint8_t lds[64 * MSG_STRIDE];
-    size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x;
-    const int jobs = k + 1;
-    if (gid >= nproofs * jobs) return;
-    size_t pr = gid / jobs;
-    int job = (int)(gid % jobs);
-    if (bad[pr]) return;
-    uint8_t* buf = lds + threadIdx.x * MSG_STRIDE;
+__device__ __forceinline__ void bpv_hash2_job(size_t pr, int job, uint8_t* buf, int k, int m, const affine_mem* __restrict__ pts,
+                                              const affine_mem* fixaff, fq* chal) {
     const int NPT = 4 + 2 * k + m;
     const affine_mem* P = pts + pr * NPT;
     int pos = 0;
@@ -300,6 +295,16 @@ __global__ __launch_bounds__(64) void k_bpv_hash2(int k, int m, size_t nproofs, 
         msg_put_point(buf, pos, fixaff[pr * 2 + 1]);
         chal[pr * CH_COUNT(k) + CH_XJ + j] = msg_result_scalar(buf, pos);
     }
+}
+__global__ __launch_bounds__(64) void k_bpv_hash2(int k, int m, size_t nproofs, const affine_mem* __restrict__ pts,
+                                                  const affine_mem* __restrict__ fixaff, fq* __restrict__ chal, const int* __restrict__ bad) {
+    __shared__ __align__(4) uint8_t lds[64 * MSG_STRIDE];
+    size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const int jobs = k + 1;
+    if (gid >= nproofs * jobs) return;
+    size_t pr = gid / jobs;
+    if (bad[pr]) return;
+    bpv_hash2_job(pr, (int)(gid % jobs), lds + threadIdx.x * MSG_STRIDE, k, m, pts, fixaff, chal);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -352,6 +357,26 @@ __device__ __forceinline__ void bpv_split_tables(fqm* cs, int k, int m) {
     }
 }
 
+// the same tables entry by entry, for callers with lanes to spare (k_bpv_chain): entry e of the 2 (2^LO + 2^HI) is a direct
+// product of its index bits' factors (the values are the same elements of F_q whichever order they are multiplied in)
+__device__ __forceinline__ void bpv_split_entry(fqm* cs, int k, int m, int e) {
+    const int LO = CS_LOBITS(k), HI = CS_HIBITS(k), nlo = 1 << LO, nhi = 1 << HI;
+    const bool ytab = e >= nlo + nhi;
+    if (ytab) e -= nlo + nhi;
+    const bool hi = e >= nlo;
+    const int j = hi ? e - nlo : e, bits = hi ? HI : LO, t0 = hi ? LO : 0;
+    fqm p = fqm_one();
+    if (ytab) {
+        for (int t = 0; t < bits; t++)
+            if ((j >> t) & 1) p = fqm_mul(p, cs[CS_YINVP(k) + t0 + t]);
+        cs[(hi ? CS_YHI(k, m) : CS_YLO(k, m)) + j] = p;
+    } else {
+        for (int t = 0; t < bits; t++) p = fqm_mul(p, cs[(((j >> t) & 1) ? CS_XJ : CS_XINV(k)) + (k - 1 - t0 - t)]);
+        cs[(hi ? CS_SHI(k, m) : CS_SLO(k, m)) + j] = p;
+    }
+}
+
+template <bool SPLIT = true>
 __device__ __forceinline__ void bpv_consts_body(size_t pr, const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k,
                                                 size_t nproofs, const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF,
                                                 fqm* __restrict__ scF, fq* __restrict__ varS, fqm* __restrict__ cst, int* __restrict__ bad) {
@@ -454,7 +479,7 @@ __device__ __forceinline__ void bpv_consts_body(size_t pr, const uint8_t* __rest
     cs[CS_Z] = z_m;
     cs[CS_A] = a_m;
     cs[CS_B] = b_m;
-    bpv_split_tables(cs, k, m);
+    if (SPLIT) bpv_split_tables(cs, k, m);
 }
 
 __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
@@ -467,14 +492,9 @@ __global__ __launch_bounds__(64) void k_bpv_consts(const uint8_t* __restrict__ p
 // s_i = prod_t (bit_t(i) ? x_{k-1-t} : x_{k-1-t}^-1), s_i^-1 = s_{nm-1-i}; d_i = z^(2+i/n) 2^(i mod n).
 // Bulletproofs+ (wip != 0, range_proof_wip.rs:537-557) with the constants of k_wipv_consts:
 // G_i : (e r') s_i y^-i + e^2 z ; H_i : (e s') s_i^-1 - e^2 z - (e^2 y^nm z^(2(1+i/n))) 2^(i mod n) y^-i.
-__global__ __launch_bounds__(256) void k_bpv_vec(int n_bits, int m, int k, size_t nproofs, const fqm* __restrict__ cst, int c, int W,
-                                                 tdig_t* __restrict__ digF, fqm* __restrict__ scF, const int* __restrict__ bad, int wip) {
+__device__ __forceinline__ void bpv_vec_elem(size_t pr, int i, int n_bits, int m, int k, const fqm* cst, int c, int W, tdig_t* __restrict__ digF,
+                                             fqm* __restrict__ scF, int wip) {
     const int nm = n_bits * m;
-    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= nproofs * (size_t)nm) return;
-    size_t pr = gid / nm;
-    int i = (int)(gid % nm);
-    if (bad[pr]) return;
     const fqm* cs = cst + pr * CS_COUNT(k, m);
     const int LO = CS_LOBITS(k), lom = (1 << LO) - 1, him = (1 << CS_HIBITS(k)) - 1;
     const int lo = i & lom, hi = i >> LO;
@@ -505,6 +525,15 @@ __global__ __launch_bounds__(256) void k_bpv_vec(int n_bits, int m, int k, size_
     store_digits(fqm_to_fq(gs), c, W, dg + (size_t)i * W);
     store_digits(fqm_to_fq(hs), c, W, dg + (size_t)(nm + i) * W);
 }
+__global__ __launch_bounds__(256) void k_bpv_vec(int n_bits, int m, int k, size_t nproofs, const fqm* __restrict__ cst, int c, int W,
+                                                 tdig_t* __restrict__ digF, fqm* __restrict__ scF, const int* __restrict__ bad, int wip) {
+    const int nm = n_bits * m;
+    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= nproofs * (size_t)nm) return;
+    size_t pr = gid / nm;
+    if (bad[pr]) return;
+    bpv_vec_elem(pr, (int)(gid % nm), n_bits, m, k, cst, c, W, digF, scF, wip);
+}
 
 // ------------------------------------------------------------------------------------------------
 size_t bpv_chal_count(int k) { return CH_COUNT(k); }
@@ -515,12 +544,106 @@ size_t bpv_cst_count(int k, int m) { return ((size_t)CS_COUNT(k, m) * sizeof(fqm
 template <int WIP>
 __global__ void k_bpv_consts_pre(unsigned cblocks, const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
                                  const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF, fqm* __restrict__ scF, fq* __restrict__ varS,
-                                 fqm* __restrict__ cst, int* __restrict__ bad, const affine_mem* __restrict__ pts, xyzz* __restrict__ pretab, int lpp);
+                                 fqm* __restrict__ cst, int* __restrict__ bad, const affine_mem* __restrict__ pts, xyzz* __restrict__ pretab, int lpp, int nparts);
+// Small batches, the whole scalar side of a proof in ONE workgroup (64 lanes) of ONE launch: hash1 -> y*G, x_u*G -> affine ->
+// hash2 -> constants -> g_i / h_i digits, each step on as many lanes as it has independent work, LDS barriers in between
+// (the steps of one proof depend on each other, the proofs do not, so nothing crosses workgroups).  As six launches the
+// chain cost 181 us of mostly launch gaps before the constants kernel could start (profiles/r02_small_batch.txt A); the
+// workgroups nproofs.. of the same launch build the ladders' window tables (the role k_bpv_consts_pre gave them), which now
+// overlap the whole chain instead of the constants alone.  Buffers written and read in here (chal, fixaff, cst) are plain
+// pointers: their readers must see the workgroup's own earlier stores.
+__global__ __launch_bounds__(64) void k_bpv_chain(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
+                                                  const affine_mem* __restrict__ pts, const affine_mem* __restrict__ gens,
+                                                  const affine_mem* __restrict__ table, int c, int W, tdig_t* __restrict__ digF, fq* __restrict__ varS,
+                                                  fq* chal, fqm* cst, affine_mem* fixaff, int* bad, int ibase, int nm_tab, xyzz* __restrict__ pretab,
+                                                  int lpp, int nparts) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x >= nproofs) {  // window tables of the (point, slice) lanes of k_bpv_small: scalar-independent
+        const size_t g = (size_t)(blockIdx.x - nproofs) * 64 + tid;
+        const size_t pr = g / (size_t)lpp;
+        const int idx = (int)(g % (size_t)lpp);
+        const int NPT = 4 + 2 * k + m, NV = 3 + 2 * k + m;
+        const int nsl = 2 * nparts;
+        if (pr >= nproofs || idx >= nsl * NV) return;
+        const int v = idx / nsl, slice = idx % nsl;
+        const int pi = (v == 0) ? 1 : (v < 1 + 2 * k + m) ? (3 + v) : (v == 1 + 2 * k + m ? 2 : 3);
+        const affine P = affine_load(pts[pr * NPT + pi]);
+        if (affine_is_inf(P)) return;
+        ec_slice_table(P, slice, pretab + (pr * (size_t)lpp + idx) * ECMUL_NT, nparts);
+        return;
+    }
+    __shared__ __align__(4) uint8_t lds[(BPV_MAXK + 1) * MSG_STRIDE];
+    __shared__ xyzz red[16];
+    __shared__ int s_bad;
+    const size_t pr = blockIdx.x;
+    if (tid == 0) s_bad = bad[pr];
+    __syncthreads();
+    if (s_bad) return;
+    // y, x, x_u, c
+    if (tid < 4) bpv_hash1_job(pr, tid, lds + tid * MSG_STRIDE, proofs, proof_len, k, m, nm_tab, pts, gens, chal, &s_bad);
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) atomicOr(&bad[pr], 1);
+        return;
+    }
+    // y * generator (lanes 0..7) and x_u * G (lanes 8..15): windows dealt round-robin, three tree levels
+    if (tid < 16) {
+        const int which = tid >> 3, sub = tid & 7;
+        const int NB = 1 << (c - 1);
+        const fq sc = chal[pr * CH_COUNT(k) + (which ? CH_XU : CH_Y)];
+        const size_t pG = which ? (size_t)2 * nm_tab : (size_t)ibase;
+        xyzz acc = xyzz_inf();
+        uint32_t carry = 0;
+        for (int w = 0; w < W; w++) {
+            const int d = window_digit(sc, c, w, carry);
+            if ((w & 7) == sub && d != 0) {
+                affine e = affine_load(table[(pG * W + w) * NB + ((d < 0 ? -d : d) - 1)]);
+                xyzz_madd_s(acc, e, d < 0);
+            }
+        }
+        red[tid] = acc;
+    }
+    __syncthreads();
+    for (int off = 4; off >= 1; off >>= 1) {
+        if (tid < 16 && (tid & 7) < off) {
+            xyzz v = red[tid];
+            xyzz o = red[tid + off];
+            xyzz_add(v, o);
+            red[tid] = v;
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && !bpv_fixinv_body(red[0], red[8], fixaff + pr * 2)) s_bad = 1;
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) atomicOr(&bad[pr], 1);
+        return;
+    }
+    // z, x_j
+    if (tid < k + 1) bpv_hash2_job(pr, tid, lds + tid * MSG_STRIDE, k, m, pts, fixaff, chal);
+    __syncthreads();
+    if (tid == 0) bpv_consts_body<false>(pr, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W, digF, nullptr, varS, cst, bad);
+    __syncthreads();
+    for (int e = tid; e < 2 * ((1 << CS_LOBITS(k)) + (1 << CS_HIBITS(k))); e += 64) bpv_split_entry(cst + pr * CS_COUNT(k, m), k, m, e);
+    __syncthreads();
+    const int nm = n_bits * m;
+    for (int i = tid; i < nm; i += 64) bpv_vec_elem(pr, i, n_bits, m, k, cst, c, W, digF, nullptr, 0);
+}
+
 hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
                                       const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fqm* scF, fq* varS, fq* chal,
                                       fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st, int ibase, int nm_tab, xyzz* pretab,
-                                      int lpp) {
+                                      int lpp, int nparts) {
     const int nm = n_bits * m;
+    static const bool unchained = bp_tune("BP_VERIFY_SMALL_UNCHAINED") != nullptr;  // A/B: the six-launch form
+    // small batch: the whole chain and the window tables in one launch, while chain and table workgroups together stay at one wave
+    // per SIMD (n=64 m=1, one call alone: 512 proofs 0.99 -> 0.82 ms, 256 proofs 1.00 -> 0.79; 1024 proofs 1.17 -> 1.42)
+    if (pretab && lpp > 0 && !scF && k <= BPV_MAXK && !unchained && nproofs * (size_t)lpp <= 32768) {
+        const unsigned blocks = (unsigned)(nproofs + (nproofs * (size_t)lpp + 63) / 64);
+        hipLaunchKernelGGL(k_bpv_chain, dim3(blocks), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, pts, gens, table, c, W, digF, varS, chal,
+                           reinterpret_cast<fqm*>(cst), fixaff, bad, ibase, nm_tab, pretab, lpp, nparts);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_bpv_hash1, dim3((unsigned)((nproofs * 4 + 63) / 64)), dim3(64), 0, st, proofs, proof_len, k, m, nm_tab, nproofs, pts, gens,
                        chal, bad);  // nm_tab: G, H sit after the table's nm_tab-long vectors (>= nm: the proof uses their prefixes)
     hipLaunchKernelGGL(k_bpv_fixmul, dim3((unsigned)((nproofs + 256 / (2 * FM_SUB) - 1) / (256 / (2 * FM_SUB)))), dim3(256), 0, st, k, nm_tab, nproofs, table, c, W, chal, fixres, bad, 2, ibase);
@@ -529,7 +652,7 @@ hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, i
     const unsigned cblocks = (unsigned)((nproofs + 63) / 64);
     if (pretab && lpp > 0)  // + the ladders' window tables in the same launch (k_bpv_consts_pre)
         hipLaunchKernelGGL((k_bpv_consts_pre<0>), dim3(cblocks + (unsigned)((nproofs * (size_t)lpp + 63) / 64)), dim3(64), 0, st, cblocks, proofs,
-                           proof_len, n_bits, m, k, nproofs, chal, c, W, digF, scF, varS, reinterpret_cast<fqm*>(cst), bad, pts, pretab, lpp);
+                           proof_len, n_bits, m, k, nproofs, chal, c, W, digF, scF, varS, reinterpret_cast<fqm*>(cst), bad, pts, pretab, lpp, nparts);
     else
         hipLaunchKernelGGL(k_bpv_consts, dim3(cblocks), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W, digF, scF, varS,
                            reinterpret_cast<fqm*>(cst), bad);
@@ -731,7 +854,7 @@ template <int WIP>
 __global__ __launch_bounds__(64) void k_bpv_consts_pre(unsigned cblocks, const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k,
                                                        size_t nproofs, const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF,
                                                        fqm* __restrict__ scF, fq* __restrict__ varS, fqm* __restrict__ cst, int* __restrict__ bad,
-                                                       const affine_mem* __restrict__ pts, xyzz* __restrict__ pretab, int lpp) {
+                                                       const affine_mem* __restrict__ pts, xyzz* __restrict__ pretab, int lpp, int nparts) {
     if (blockIdx.x < cblocks) {
         const size_t pr = (size_t)blockIdx.x * 64 + threadIdx.x;
         if (WIP)
@@ -744,19 +867,20 @@ __global__ __launch_bounds__(64) void k_bpv_consts_pre(unsigned cblocks, const u
     const size_t pr = g / (size_t)lpp;
     const int idx = (int)(g % (size_t)lpp);  // one (point, slice) per lane: lpp >= 4 NV (bpv_slice_lanes)
     const int NPT = (WIP ? 3 : 4) + 2 * k + m, NV = (WIP ? 2 : 3) + 2 * k + m;
-    if (pr >= nproofs || idx >= 4 * NV) return;
-    const int v = idx >> 2, slice = idx & 3;
+    const int nsl = 2 * nparts;
+    if (pr >= nproofs || idx >= nsl * NV) return;
+    const int v = idx / nsl, slice = idx % nsl;
     // variable point order: S, L_0.., R_0.., V_0.., T1, T2  ->  index into pts (as in k_bpv_msm)
     const int pi = WIP ? 1 + v : (v == 0) ? 1 : (v < 1 + 2 * k + m) ? (3 + v) : (v == 1 + 2 * k + m ? 2 : 3);
     const affine P = affine_load(pts[pr * NPT + pi]);
     if (affine_is_inf(P)) return;  // (a malformed proof's slot: its verdict never reads the table)
-    ec_slice_table(P, slice, pretab + (pr * (size_t)lpp + idx) * ECMUL_NT);
+    ec_slice_table(P, slice, pretab + (pr * (size_t)lpp + idx) * ECMUL_NT, nparts);
 }
 
 hipError_t launch_wipv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
                                        const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fqm* scF, fq* varS, fq* chal,
                                        fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st, int ibase, int nm_tab, xyzz* pretab,
-                                       int lpp) {
+                                       int lpp, int nparts) {
     const int nm = n_bits * m;
     hipLaunchKernelGGL(k_wipv_hash1, dim3((unsigned)((nproofs * (k + 2) + 63) / 64)), dim3(64), 0, st, proofs, proof_len, k, m, nm_tab, nproofs, pts,
                        gens, chal, bad);
@@ -767,7 +891,7 @@ hipError_t launch_wipv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, 
     const unsigned cblocks = (unsigned)((nproofs + 63) / 64);
     if (pretab && lpp > 0)
         hipLaunchKernelGGL((k_bpv_consts_pre<1>), dim3(cblocks + (unsigned)((nproofs * (size_t)lpp + 63) / 64)), dim3(64), 0, st, cblocks, proofs,
-                           proof_len, n_bits, m, k, nproofs, chal, c, W, digF, scF, varS, reinterpret_cast<fqm*>(cst), bad, pts, pretab, lpp);
+                           proof_len, n_bits, m, k, nproofs, chal, c, W, digF, scF, varS, reinterpret_cast<fqm*>(cst), bad, pts, pretab, lpp, nparts);
     else
         hipLaunchKernelGGL(k_wipv_consts, dim3(cblocks), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W, digF, scF, varS,
                            reinterpret_cast<fqm*>(cst), bad);

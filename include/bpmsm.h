@@ -201,8 +201,9 @@ int bp_rangeproof_verify_batch_rlc(bp_ctx* ctx, const bp_gens* gens, int n_bits,
                                    const uint8_t* coms_xy, size_t nproofs, const uint8_t seed[32], uint8_t* verdicts, int* used_fallback);
 int bp_rangeproof_verify_batch_rlc_device(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const void* d_proofs, size_t proof_len,
                                           const void* d_coms_xy, size_t nproofs, const uint8_t seed[32], void* d_verdicts, int* used_fallback);
-/* Tuning knob: lanes per proof in the verifier's MSM kernel (2, 4, 8, 16, 32 or 64; 0 = chosen by batch size; -4 = the
- * small-batch kernel with four lanes per proof-specific point, which 0 picks by itself when the batch is latency-bound). */
+/* Tuning knob: lanes per proof in the verifier's MSM kernel (2, 4, 8, 16, 32 or 64; 0 = chosen by batch size; -4 / -8 = the
+ * small-batch kernels with four / eight lanes per proof-specific point, which 0 picks by itself when the batch is
+ * latency-bound: eight up to 65536 / (8 points' lanes) proofs, four up to twice that). */
 void bp_verify_set_lanes(bp_ctx* ctx, int lanes);
 /* Overlap of successive bp_rangeproof_verify_batch_device / bp_wip_rangeproof_verify_batch_device calls.
  * DEFAULT ON since round 2 (an ABI-visible change of behaviour: round 1 ran every call on the context's stream).

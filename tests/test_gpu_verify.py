@@ -16,7 +16,7 @@ def _gens(ctx, n, m, window_bits=0):
 
 
 @pytest.mark.parametrize("idx", range(5))
-@pytest.mark.parametrize("lanes", [4, 8, 16, 64, -4])
+@pytest.mark.parametrize("lanes", [4, 8, 16, 64, -4, -8])
 def test_bp_cases_valid_and_tampered(ctx, idx, lanes):
     case = bp_cases()[idx]
     n, m = case["n"], case["m"]
@@ -173,7 +173,7 @@ def _case_batch(case):
 
 
 @pytest.mark.parametrize("idx", range(4))
-@pytest.mark.parametrize("lanes", [0, 4, 16, 64])
+@pytest.mark.parametrize("lanes", [0, 4, 16, 64, -4, -8])
 def test_bpplus_batch_cases_valid_and_tampered(ctx, idx, lanes):
     """`RangeProofWIP::aggregated_verify` (range_proof_wip.rs:388-609) on the GPU for a batch: the golden proofs
     (n*m = 8 .. 256) and their tampered variants get the oracle's verdicts, at every lanes-per-proof setting."""
