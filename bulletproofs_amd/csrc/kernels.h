@@ -113,8 +113,23 @@ hipError_t launch_pv_lr(size_t nproofs, int n_bits, int m, const uint8_t* tapes,
 hipError_t launch_pv_round(size_t nproofs, int nm, int n, int c, int W, const uint8_t* xu_be, const fqm* a, const fqm* b, const fqm* cG,
                            const fqm* cH, pv_ent* ent, size_t stride, hipStream_t st);
 hipError_t launch_pv_fold(size_t nproofs, int nm, int n, const uint8_t* xj_be, fqm* a, fqm* b, fqm* cG, fqm* cH, hipStream_t st);
-hipError_t launch_pv_msm(size_t njobs, const affine_mem* table, int c, const pv_ent* ent, size_t stride, int cnt0, int cnt1, xyzz* out,
-                         hipStream_t st);
+#define PV_MSM_MAXPARTS 8  // workgroups per job of k_pv_msm at most: `partial` holds njobs * PV_MSM_MAXPARTS sums
+hipError_t launch_pv_msm(size_t njobs, const affine_mem* table, int c, const pv_ent* ent, size_t stride, int cnt0, int cnt1, xyzz* partial,
+                         xyzz* out, hipStream_t st);
+// Bulletproofs+ batch prover (RangeProofWIP::prove x N)
+hipError_t launch_pw_init(size_t nproofs, int nm, int c, int W, const uint8_t* tapes, size_t tape_len, const uint8_t* bits, pv_ent* ent,
+                          size_t stride, hipStream_t st);
+hipError_t launch_pw_setup(size_t nproofs, int n_bits, int m, const uint8_t* tapes, size_t tape_len, const uint8_t* yz_be,
+                           const uint8_t* blindings_be, const uint8_t* bits, fqm* yp, fqm* a, fqm* b, fqm* cG, fqm* cH, fqm* alpha_hat, fqm* yinv,
+                           hipStream_t st);
+hipError_t launch_pw_round(size_t nproofs, int nm, int n, int j, int c, int W, const uint8_t* tapes, size_t tape_len, const fqm* yp, const fqm* yinv,
+                           const fqm* a, const fqm* b, const fqm* cG, const fqm* cH, pv_ent* ent, size_t stride, hipStream_t st);
+hipError_t launch_pw_fold(size_t nproofs, int nm, int n, int j, const uint8_t* tapes, size_t tape_len, const uint8_t* xj_be, const fqm* yp,
+                          const fqm* yinv, fqm* a, fqm* b, fqm* cG, fqm* cH, fqm* alpha_hat, hipStream_t st);
+hipError_t launch_pw_last(size_t nproofs, int nm, int k, int c, int W, const uint8_t* tapes, size_t tape_len, const uint8_t* yz_be, const fqm* a,
+                          const fqm* b, const fqm* cG, const fqm* cH, pv_ent* ent, size_t stride, hipStream_t st);
+hipError_t launch_pw_finish(size_t nproofs, int nm, int k, const uint8_t* tapes, size_t tape_len, const uint8_t* e_be, const fqm* a, const fqm* b,
+                            const fqm* alpha_hat, uint8_t* out_be, hipStream_t st);
 hipError_t launch_pv_final(size_t nproofs, int nm, const fqm* a, const fqm* b, uint8_t* out_be, hipStream_t st);
 // lanes per proof (> 0) when a batch with tp lanes takes the one-launch small-batch MSM (k_bpv_small) and its window tables
 // are built beside the constants kernel (k_bpv_consts_pre); 0 otherwise

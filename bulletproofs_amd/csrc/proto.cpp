@@ -1723,7 +1723,7 @@ int prove_batch_device_chunk(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
     const size_t o_tape = carve(N * tape_len), o_bits = carve(N * nm), o_blind = carve(N * (size_t)m * 32), o_SL = carve(N * nm * sizeof(fqm)),
                  o_SR = carve(N * nm * sizeof(fqm)), o_yi = carve(N * nm * sizeof(fqm)), o_a = carve(N * nm * sizeof(fqm)),
                  o_b = carve(N * nm * sizeof(fqm)), o_cG = carve(N * nm * sizeof(fqm)), o_cH = carve(N * nm * sizeof(fqm)),
-                 o_zpow = carve(N * (size_t)m * sizeof(fqm)), o_yinv = carve(N * sizeof(fqm)), o_ent = carve(2 * N * stride * sizeof(pv_ent)), o_res = carve(2 * N * sizeof(xyzz)), o_aff = carve(2 * N * sizeof(affine_mem)),
+                 o_zpow = carve(N * (size_t)m * sizeof(fqm)), o_yinv = carve(N * sizeof(fqm)), o_ent = carve(2 * N * stride * sizeof(pv_ent)), o_res = carve(2 * N * sizeof(xyzz)), o_part = carve(2 * N * PV_MSM_MAXPARTS * sizeof(xyzz)), o_aff = carve(2 * N * sizeof(affine_mem)),
                  o_ptbe = carve(2 * N * 64), o_yz = carve(N * 64), o_x = carve(N * 32), o_xu = carve(N * 32), o_xj = carve(N * 32),
                  o_out = carve(N * 96);
     RC(ctx->proto[0].reserve(off));
@@ -1756,7 +1756,7 @@ int prove_batch_device_chunk(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
     pv_ent* ent = (pv_ent*)(D + o_ent);
     // the table MSMs of one step: njobs entry lists (cnt0 entries in even jobs, cnt1 in odd ones) -> affine big-endian points on the host
     auto msm_step = [&](size_t njobs, size_t cnt0, size_t cnt1) -> int {
-        HIPCHK(launch_pv_msm(njobs, gens->d_table, c, ent, stride, (int)cnt0, (int)cnt1, (xyzz*)(D + o_res), s), "table msm");
+        HIPCHK(launch_pv_msm(njobs, gens->d_table, c, ent, stride, (int)cnt0, (int)cnt1, (xyzz*)(D + o_part), (xyzz*)(D + o_res), s), "table msm");
         HIPCHK(launch_xyzz_to_affine((const xyzz*)(D + o_res), (affine_mem*)(D + o_aff), njobs, s), "normalize");
         HIPCHK(launch_export_points((const affine_mem*)(D + o_aff), D + o_ptbe, njobs, s), "export");
         HIPCHK(hipMemcpyAsync(h_pts, D + o_ptbe, njobs * 64, hipMemcpyDeviceToHost, s), "d2h points");
@@ -1865,6 +1865,137 @@ int prove_batch_device_chunk(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
     return BP_OK;
 }
 
+// The same for Bulletproofs+ (`RangeProofWIP::prove`, range_proof_wip.rs:101-274; weighted_inner_product.rs:47-268):
+// A -> y -> yG -> z -> k rounds (L_j, R_j -> x_j) -> A', B' -> e -> r', s', delta'.
+int prove_batch_device_chunk_wip(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, size_t N, const uint8_t* secrets_be,
+                                 const uint8_t* blindings_be, const uint8_t* tapes, size_t tape_len, uint8_t* proofs_out, size_t proof_len, int* st,
+                                 size_t hthreads) {
+    const size_t n = (size_t)n_bits, nm = n * (size_t)m;
+    const int k = log2_exact(nm), W = gens->W, c = gens->c;
+    const size_t ntape = 1 + 2 * (size_t)k + 4;
+    const size_t stride = (2 * nm + 2) * (size_t)W;  // entries of the longest job (A')
+    hipStream_t s = ctx->stream;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const size_t o_tape = carve(N * tape_len), o_bits = carve(N * nm), o_blind = carve(N * (size_t)m * 32), o_yp = carve(N * nm * sizeof(fqm)),
+                 o_a = carve(N * nm * sizeof(fqm)), o_b = carve(N * nm * sizeof(fqm)), o_cG = carve(N * nm * sizeof(fqm)),
+                 o_cH = carve(N * nm * sizeof(fqm)), o_alpha = carve(N * sizeof(fqm)), o_yinv = carve(N * sizeof(fqm)),
+                 o_ent = carve(2 * N * stride * sizeof(pv_ent)), o_res = carve(2 * N * sizeof(xyzz)), o_part = carve(2 * N * PV_MSM_MAXPARTS * sizeof(xyzz)), o_aff = carve(2 * N * sizeof(affine_mem)),
+                 o_ptbe = carve(2 * N * 64), o_yz = carve(N * 64), o_x = carve(N * 32), o_out = carve(N * 96);
+    RC(ctx->proto[0].reserve(off));
+    uint8_t* D = (uint8_t*)ctx->proto[0].p;
+    RC(pin_reserve(ctx, 2 * N * 64 + N * 96 + N * 64 + N * nm));
+    uint8_t* h_pts = (uint8_t*)ctx->h_pin;  // [2N][64] points of a step
+    uint8_t* h_sc = h_pts + 2 * N * 64;     // [N][96] r', s', delta'
+    uint8_t* h_up = h_sc + N * 96;          // [N][64] challenges up
+    uint8_t* h_bits = h_up + N * 64;        // [N][nm]
+    std::vector<uint8_t> ok(N, 1);
+    parallel_for(N, hthreads, [&](size_t i) {
+        const uint8_t* tp = tapes + i * tape_len;
+        for (size_t j = 0; j < ntape; j++) {  // Tape::next: canonical, non-zero
+            const uint8_t* q = tp + 32 * j;
+            bool z = true;
+            for (int b = 0; b < 32; b++) z = z && q[b] == 0;
+            if (z || !fq_be_is_canonical(q)) ok[i] = 0;
+        }
+        std::vector<int> bits = secret_bits(secrets_be + i * (size_t)m * 32, m, n);
+        for (size_t j = 0; j < nm; j++) h_bits[i * nm + j] = (uint8_t)bits[j];
+    });
+    HIPCHK(hipMemcpyAsync(D + o_tape, tapes, N * tape_len, hipMemcpyHostToDevice, s), "h2d tapes");
+    HIPCHK(hipMemcpyAsync(D + o_bits, h_bits, N * nm, hipMemcpyHostToDevice, s), "h2d bits");
+    HIPCHK(hipMemcpyAsync(D + o_blind, blindings_be, N * (size_t)m * 32, hipMemcpyHostToDevice, s), "h2d blindings");
+    fqm *yp = (fqm*)(D + o_yp), *a = (fqm*)(D + o_a), *b = (fqm*)(D + o_b), *cG = (fqm*)(D + o_cG), *cH = (fqm*)(D + o_cH),
+        *alpha = (fqm*)(D + o_alpha), *yinv = (fqm*)(D + o_yinv);
+    pv_ent* ent = (pv_ent*)(D + o_ent);
+    auto msm_step = [&](size_t njobs, size_t cnt0, size_t cnt1) -> int {
+        HIPCHK(launch_pv_msm(njobs, gens->d_table, c, ent, stride, (int)cnt0, (int)cnt1, (xyzz*)(D + o_part), (xyzz*)(D + o_res), s), "table msm");
+        HIPCHK(launch_xyzz_to_affine((const xyzz*)(D + o_res), (affine_mem*)(D + o_aff), njobs, s), "normalize");
+        HIPCHK(launch_export_points((const affine_mem*)(D + o_aff), D + o_ptbe, njobs, s), "export");
+        HIPCHK(hipMemcpyAsync(h_pts, D + o_ptbe, njobs * 64, hipMemcpyDeviceToHost, s), "d2h points");
+        HIPCHK(hipStreamSynchronize(s), "sync");
+        return BP_OK;
+    };
+    auto inf = [](const uint8_t* p) { return host_is_inf(p); };
+    const uint8_t* Gh = &gens->host_be[2 * nm * 64];
+    const uint8_t* Hh = &gens->host_be[(2 * nm + 1) * 64];
+    std::vector<Pt> A(N), At(N), Bt(N);
+    std::vector<Fq> y(N);
+    std::vector<std::vector<Pt>> Ls(N, std::vector<Pt>(k)), Rs(N, std::vector<Pt>(k));
+    // A   (range_proof_wip.rs:150-165), y = H(A)   (:167)
+    HIPCHK(launch_pw_init(N, (int)nm, c, W, D + o_tape, tape_len, D + o_bits, ent, stride, s), "pw_init");
+    RC(msm_step(N, nm + W, nm + W));
+    parallel_for(N, hthreads, [&](size_t i) {
+        memcpy(A[i].b, h_pts + 64 * i, 64);
+        if (inf(A[i].b)) ok[i] = 0;
+        y[i] = Transcript().point(A[i].b).result_scalar();
+        if (y[i].is_zero()) ok[i] = 0;
+        (ok[i] ? y[i] : Fq(1)).to_be(h_up + 32 * i);
+    });
+    // yG = Point::generator() * y, z = H(A, yG)   (:169-171)
+    HIPCHK(hipMemcpyAsync(D + o_x, h_up, N * 32, hipMemcpyHostToDevice, s), "h2d y");
+    HIPCHK(launch_pv_term(N, c, W, gens->ibase, D + o_x, ent, stride, s), "pv_term");
+    RC(msm_step(N, W, W));
+    parallel_for(N, hthreads, [&](size_t i) {
+        if (inf(h_pts + 64 * i)) ok[i] = 0;
+        Fq z = Transcript().point(A[i].b).point(h_pts + 64 * i).result_scalar();
+        (ok[i] ? y[i] : Fq(1)).to_be(h_up + 64 * i);
+        z.to_be(h_up + 64 * i + 32);
+    });
+    HIPCHK(hipMemcpyAsync(D + o_yz, h_up, N * 64, hipMemcpyHostToDevice, s), "h2d yz");
+    HIPCHK(launch_pw_setup(N, n_bits, m, D + o_tape, tape_len, D + o_yz, D + o_blind, D + o_bits, yp, a, b, cG, cH, alpha, yinv, s), "pw_setup");
+    HIPCHK(hipStreamSynchronize(s), "sync");  // h_up is rewritten by the first round
+    // WeightedInnerProdArg::prove   (weighted_inner_product.rs:47-268)
+    size_t len = nm;
+    for (int j = 0; j < k; j++, len /= 2) {
+        HIPCHK(launch_pw_round(N, (int)nm, (int)len, j, c, W, D + o_tape, tape_len, yp, yinv, a, b, cG, cH, ent, stride, s), "pw_round");
+        RC(msm_step(2 * N, (nm + 2) * W, (nm + 2) * W));
+        parallel_for(N, hthreads, [&](size_t i) {
+            memcpy(Ls[i][j].b, h_pts + 128 * i, 64);
+            memcpy(Rs[i][j].b, h_pts + 128 * i + 64, 64);
+            if (inf(Ls[i][j].b) || inf(Rs[i][j].b)) ok[i] = 0;
+            Fq x = Transcript().point(Ls[i][j].b).point(Rs[i][j].b).point(Gh).point(Hh).result_scalar();  // :158
+            if (x.is_zero()) ok[i] = 0;
+            (x.is_zero() ? Fq(1) : x).to_be(h_up + 32 * i);
+        });
+        HIPCHK(hipMemcpyAsync(D + o_x, h_up, N * 32, hipMemcpyHostToDevice, s), "h2d xj");
+        HIPCHK(launch_pw_fold(N, (int)nm, (int)len, j, D + o_tape, tape_len, D + o_x, yp, yinv, a, b, cG, cH, alpha, s), "pw_fold");
+        HIPCHK(hipStreamSynchronize(s), "sync");
+    }
+    // A', B'   (:213-239), e = H(A', B', g, h)   (:243)
+    HIPCHK(launch_pw_last(N, (int)nm, k, c, W, D + o_tape, tape_len, D + o_yz, a, b, cG, cH, ent, stride, s), "pw_last");
+    RC(msm_step(2 * N, (2 * nm + 2) * W, 2 * (size_t)W));
+    parallel_for(N, hthreads, [&](size_t i) {
+        memcpy(At[i].b, h_pts + 128 * i, 64);
+        memcpy(Bt[i].b, h_pts + 128 * i + 64, 64);
+        if (inf(At[i].b) || inf(Bt[i].b)) ok[i] = 0;
+        Transcript().point(At[i].b).point(Bt[i].b).point(Gh).point(Hh).result_scalar().to_be(h_up + 32 * i);
+    });
+    HIPCHK(hipMemcpyAsync(D + o_x, h_up, N * 32, hipMemcpyHostToDevice, s), "h2d e");
+    HIPCHK(launch_pw_finish(N, (int)nm, k, D + o_tape, tape_len, D + o_x, a, b, alpha, D + o_out, s), "pw_finish");
+    HIPCHK(hipMemcpyAsync(h_sc, D + o_out, N * 96, hipMemcpyDeviceToHost, s), "d2h scalars");
+    HIPCHK(hipStreamSynchronize(s), "sync");
+    parallel_for(N, hthreads, [&](size_t i) {
+        if (!ok[i]) {
+            st[i] = BP_EINVAL;
+            return;
+        }
+        uint8_t* q = proofs_out + i * proof_len;
+        host_compress(A[i].b, q);
+        q += 33;
+        for (int j = 0; j < k; j++, q += 33) host_compress(Ls[i][j].b, q);
+        for (int j = 0; j < k; j++, q += 33) host_compress(Rs[i][j].b, q);
+        host_compress(At[i].b, q);
+        host_compress(Bt[i].b, q + 33);
+        memcpy(q + 66, h_sc + 96 * i, 96);  // r', s', delta'
+        st[i] = BP_OK;
+    });
+    return BP_OK;
+}
+
 }  // namespace
 extern "C" {
 
@@ -1901,10 +2032,12 @@ static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
     };
     // Bulletproofs on the device: the per-proof vectors are kernels over [proof][i] (prove_kernels.hip), the host keeps the
     // transcript.  A step of one chunk is launch -> copy back -> hash -> copy up, so the GPU would idle through every host
-    // part: the batch is cut into chunks that run on up to four lanes (host thread + stream each) whose steps overlap.
-    // (Bulletproofs+ keeps the host-thread path below.)
-    if (!wip && nm <= 4096 && !bp_tune("BP_PROVE_HOST")) {
-        size_t lanes = 4;
+    // part: the batch is cut into chunks that run on two lanes (host thread + stream each) whose steps overlap (measured 1 / 2 / 4
+    // lanes: n=64 m=1 4096 proofs 219 / 253 / 256 K proofs/s, n=64 m=16 512 proofs 14.1 / 14.4 / 14.0 K, BP+ n=64 m=64 256 proofs
+    // 5.3 / 6.0 / 5.2 K - once the table MSMs fill the GPU more lanes only shorten each launch).
+    // (The host-thread path below stays for tuning builds' A/B runs and for generator sets beyond 4096 terms.)
+    if (nm <= 4096 && tape_len >= 32 * (wip ? (size_t)(1 + 2 * k + 4) : 2 * nm + 4) && !bp_tune("BP_PROVE_HOST")) {
+        size_t lanes = 2;
         if (const char* e = bp_tune("BP_PROVE_LANES")) lanes = (size_t)atol(e) >= 1 && (size_t)atol(e) <= 8 ? (size_t)atol(e) : lanes;
         size_t maxchunk = ((size_t)1 << 20) / nm;  // workspace bound: ~0.4 KB of entries per generator term
         if (maxchunk > 4096) maxchunk = 4096;
@@ -1929,8 +2062,9 @@ static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
             }
             for (size_t ci = l; ci < nchunks && lane_rc[l] == BP_OK; ci += lanes) {
                 const size_t base = ci * chunk, cnt = nproofs - base < chunk ? nproofs - base : chunk;
-                lane_rc[l] = prove_batch_device_chunk(lctx, gens, n_bits, m, cnt, secrets_be + base * (size_t)m * 32, blindings_be + base * (size_t)m * 32,
-                                                      tapes + base * tape_len, tape_len, proofs_out + base * proof_len, proof_len, &stv[base], hthreads);
+                lane_rc[l] = (wip ? prove_batch_device_chunk_wip : prove_batch_device_chunk)(
+                    lctx, gens, n_bits, m, cnt, secrets_be + base * (size_t)m * 32, blindings_be + base * (size_t)m * 32, tapes + base * tape_len, tape_len,
+                    proofs_out + base * proof_len, proof_len, &stv[base], hthreads);
             }
             if (lane_rc[l] != BP_OK) lane_msg[l] = bp_last_error();
         };

@@ -270,13 +270,16 @@ __global__ __launch_bounds__(PV_T) void k_pv_fold(int nm, int n, const uint8_t* 
 // The table MSMs of one step: job j sums its cnt (even jobs: cnt0, odd jobs: cnt1) entries ent[j stride ..], one table
 // gather and one mixed addition per entry (the table of bp_gens: [slot][2^(c-1)] affine multiples), TP lanes per job with
 // the next gather in flight behind the current addition (as bpv_fix_lane_sum, verify_kernels.hip), LDS tree, one XYZZ sum
-// per job.
+// per (job, part): with few long jobs (aggregated proofs: 10^5 entries each) a job is dealt over `parts` workgroups of 256
+// lanes, whose partial sums k_pv_msm_combine adds.
 template <int TP>
 __global__ __launch_bounds__(256, 3) void k_pv_msm(size_t njobs, const affine_mem* __restrict__ table, int c, const pv_ent* __restrict__ ent,
-                                                   size_t stride, int cnt0, int cnt1, xyzz* __restrict__ out) {
+                                                   size_t stride, int cnt0, int cnt1, int parts, xyzz* __restrict__ out) {
     __shared__ xyzz red[256];
     const int tid = threadIdx.x, lane = tid % TP;
-    const size_t job = (size_t)blockIdx.x * (256 / TP) + tid / TP;
+    const size_t unit = (size_t)blockIdx.x * (256 / TP) + tid / TP;  // (job, part)
+    const size_t job = unit / (size_t)parts;
+    const int part = (int)(unit % (size_t)parts), step = TP * parts;
     xyzz acc = xyzz_inf();
     if (job < njobs) {
         const int n = (job & 1) ? cnt1 : cnt0;
@@ -293,16 +296,17 @@ __global__ __launch_bounds__(256, 3) void k_pv_msm(size_t njobs, const affine_me
                 xyzz_madd_s(acc, p, t.d < 0);
             }
         };
-        pv_ent tA = fetch(lane), tB = fetch(lane + TP);
+        const int first = lane + TP * part;
+        pv_ent tA = fetch(first), tB = fetch(first + step);
         affine_mem A = gather(tA), B;
-        for (int idx = lane; idx < n; idx += 2 * TP) {
-            pv_ent tN = fetch(idx + 2 * TP);
+        for (int idx = first; idx < n; idx += 2 * step) {
+            pv_ent tN = fetch(idx + 2 * step);
             B = gather(tB);
             add(A, tA, idx);
             tA = tN;
-            tN = fetch(idx + 3 * TP);
+            tN = fetch(idx + 3 * step);
             A = gather(tA);
-            add(B, tB, idx + TP);
+            add(B, tB, idx + step);
             tB = tN;
         }
     }
@@ -320,7 +324,17 @@ __global__ __launch_bounds__(256, 3) void k_pv_msm(size_t njobs, const affine_me
         }
         acc = red[tid];
     }
-    if (lane == 0 && job < njobs) out[job] = acc;
+    if (lane == 0 && job < njobs) out[unit] = acc;
+}
+__global__ void k_pv_msm_combine(size_t njobs, int parts, const xyzz* __restrict__ partial, xyzz* __restrict__ out) {
+    const size_t job = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= njobs) return;
+    xyzz acc = partial[job * parts];
+    for (int p = 1; p < parts; p++) {
+        xyzz o = partial[job * parts + p];
+        xyzz_add(acc, o);
+    }
+    out[job] = acc;
 }
 
 __global__ void k_pv_final(size_t nproofs, int nm, const fqm* __restrict__ a, const fqm* __restrict__ b, uint8_t* __restrict__ out_be /* [N][64] */) {
@@ -328,6 +342,182 @@ __global__ void k_pv_final(size_t nproofs, int nm, const fqm* __restrict__ a, co
     if (pr >= nproofs) return;
     fq_to_be(out_be + 64 * pr, fqm_to_fq(a[pr * nm]));
     fq_to_be(out_be + 64 * pr + 32, fqm_to_fq(b[pr * nm]));
+}
+
+// ====================================================================================================================
+// Bulletproofs+ : scalar side of the BATCH prover `RangeProofWIP::prove` x N
+// (/root/reference/src/proofs/range_proof_wip.rs:101-274, weighted_inner_product.rs:47-268), same shape as above.
+// Tape of a proof (reference draw order, range_proof_wip.rs:150, weighted_inner_product.rs:106, 134, 213-219):
+//   alpha, (d_L, d_R) per round, r, s, delta, eta
+#define TW_ALPHA 0
+#define TW_DL(j) (1 + 2 * (j))
+#define TW_DR(j) (2 + 2 * (j))
+#define TW_R(k) (1 + 2 * (k))
+#define TW_S(k) (2 + 2 * (k))
+#define TW_DELTA(k) (3 + 2 * (k))
+#define TW_ETA(k) (4 + 2 * (k))
+
+// A = alpha h + sum_{bit} g_i - sum_{!bit} h_i (range_proof_wip.rs:150-165): one job per proof, nm + W entries
+__global__ __launch_bounds__(PV_T) void k_pw_init(int nm, int c, int W, const uint8_t* __restrict__ tapes, size_t tape_len,
+                                                  const uint8_t* __restrict__ bits, pv_ent* __restrict__ ent, size_t stride) {
+    const size_t pr = blockIdx.x;
+    pv_ent* eA = ent + pr * stride;
+    for (int i = threadIdx.x; i < nm; i += (int)blockDim.x) {
+        const int bit = bits[pr * nm + i];
+        pv_ent u;
+        u.slot = (uint32_t)((bit ? i : nm + i) * W);
+        u.d = bit ? 1 : -1;
+        eA[i] = u;
+    }
+    if (threadIdx.x == 0) pv_digits(pv_be(tapes + pr * tape_len + 32 * TW_ALPHA), c, W, 2 * nm + 1, eA + nm);
+}
+
+// y^(i+1), the vectors of the weighted inner-product argument a = aL - z, b = aR + d_i y^(nm-i) + z (:254-260, d_i =
+// 2^(i mod n) z^(2(i/n+1)) :186-199), alpha_hat = alpha + y^(nm+1) sum_j z^(2(j+1)) gamma_j (:205-207, 262), cG = cH = 1, y^-1
+__global__ __launch_bounds__(PV_T) void k_pw_setup(int n_bits, int m, const uint8_t* __restrict__ tapes, size_t tape_len,
+                                                   const uint8_t* __restrict__ yz_be, const uint8_t* __restrict__ blindings_be,
+                                                   const uint8_t* __restrict__ bits, fqm* __restrict__ yp, fqm* __restrict__ a, fqm* __restrict__ b,
+                                                   fqm* __restrict__ cG, fqm* __restrict__ cH, fqm* __restrict__ alpha_hat, fqm* __restrict__ yinv) {
+    const size_t pr = blockIdx.x;
+    const int nm = n_bits * m;
+    const fqm y = pv_be(yz_be + 64 * pr), z = pv_be(yz_be + 64 * pr + 32), ONE = fqm_one(), zsq = fqm_mul(z, z);
+    for (int i = threadIdx.x; i < nm; i += (int)blockDim.x) {
+        yp[pr * nm + i] = pv_pow(y, (uint32_t)i + 1u);
+        const fqm aL = bits[pr * nm + i] ? ONE : fqm_zero(), aR = fqm_sub(aL, ONE);
+        const fqm d = fqm_mul(pv_pow(zsq, 1u + (uint32_t)(i / n_bits)), pv_two_pow(i % n_bits));
+        a[pr * nm + i] = fqm_sub(aL, z);
+        b[pr * nm + i] = fqm_add(aR, fqm_add(fqm_mul(d, pv_pow(y, (uint32_t)(nm - i))), z));
+        cG[pr * nm + i] = ONE;
+        cH[pr * nm + i] = ONE;
+    }
+    if (threadIdx.x == 0) {
+        fqm ipb = fqm_zero(), zp = zsq;
+        for (int j = 0; j < m; j++) {
+            ipb = fqm_add(ipb, fqm_mul(pv_be(blindings_be + 32 * (pr * m + j)), zp));
+            zp = fqm_mul(zp, zsq);
+        }
+        alpha_hat[pr] = fqm_add(pv_be(tapes + pr * tape_len + 32 * TW_ALPHA), fqm_mul(ipb, pv_pow(y, (uint32_t)nm + 1u)));
+        yinv[pr] = fqm_inv_var(y);  // (y = 0 is refused by the host before this launch)
+    }
+}
+
+// One round of WeightedInnerProdArg::prove over the ORIGINAL generators (n = current length, h = n / 2, round j):
+// c_L = <a_L, b_R>_y, c_R = <y^h a_R, b_L>_y (:97-101, 128-130) and the entries of
+//   L = <y^-h a_L, G_R> + <b_R, H_L> + c_L g + d_L h (:103-126),  R = <y^h a_R, G_L> + <b_L, H_R> + c_R g + d_R h (:131-154)
+__global__ __launch_bounds__(PV_T) void k_pw_round(int nm, int n, int j, int c, int W, const uint8_t* __restrict__ tapes, size_t tape_len,
+                                                   const fqm* __restrict__ yp, const fqm* __restrict__ yinv, const fqm* __restrict__ a,
+                                                   const fqm* __restrict__ b, const fqm* __restrict__ cG, const fqm* __restrict__ cH,
+                                                   pv_ent* __restrict__ ent, size_t stride) {
+    __shared__ fqm red[PV_T];
+    __shared__ fqm s_yninv;
+    const size_t pr = blockIdx.x;
+    const int h = n / 2;
+    const fqm* A = a + pr * nm;
+    const fqm* B = b + pr * nm;
+    const fqm* Y = yp + pr * nm;
+    const fqm yn = Y[h - 1];
+    if (threadIdx.x == 0) s_yninv = pv_pow(yinv[pr], (uint32_t)h);
+    fqm cL = fqm_zero(), cR = fqm_zero();
+    for (int i = threadIdx.x; i < h; i += (int)blockDim.x) {
+        cL = fqm_add(cL, fqm_mul(fqm_mul(A[i], B[h + i]), Y[i]));
+        cR = fqm_add(cR, fqm_mul(fqm_mul(fqm_mul(yn, A[h + i]), B[i]), Y[i]));
+    }
+    cL = pv_block_sum(cL, red);
+    cR = pv_block_sum(cR, red);
+    const fqm yninv = s_yninv;
+    pv_ent* eL = ent + (2 * pr) * stride;  // (nm + 2) W entries each
+    pv_ent* eR = ent + (2 * pr + 1) * stride;
+    for (int t = threadIdx.x; t < nm; t += (int)blockDim.x) {
+        const int r = t & (n - 1);
+        const fqm g = cG[pr * nm + t], hh = cH[pr * nm + t];
+        if (r >= h) {
+            pv_digits(fqm_mul(fqm_mul(yninv, A[r - h]), g), c, W, t, eL + (size_t)t * W);   // <y^-h a_L, G_R>
+            pv_digits(fqm_mul(B[r - h], hh), c, W, nm + t, eR + (size_t)t * W);             // <b_L, H_R>
+        } else {
+            pv_digits(fqm_mul(B[h + r], hh), c, W, nm + t, eL + (size_t)t * W);             // <b_R, H_L>
+            pv_digits(fqm_mul(fqm_mul(yn, A[h + r]), g), c, W, t, eR + (size_t)t * W);      // <y^h a_R, G_L>
+        }
+    }
+    if (threadIdx.x == 0) {
+        const uint8_t* tp = tapes + pr * tape_len;
+        pv_digits(cL, c, W, 2 * nm, eL + (size_t)nm * W);
+        pv_digits(pv_be(tp + 32 * (size_t)TW_DL(j)), c, W, 2 * nm + 1, eL + (size_t)(nm + 1) * W);
+        pv_digits(cR, c, W, 2 * nm, eR + (size_t)nm * W);
+        pv_digits(pv_be(tp + 32 * (size_t)TW_DR(j)), c, W, 2 * nm + 1, eR + (size_t)(nm + 1) * W);
+    }
+}
+
+// a' = x a_L + x^-1 y^h a_R, b' = x b_R + x^-1 b_L (:164-179), alpha += x^2 d_L + x^-2 d_R (:182-185); the base folds
+// G_hat = x^-1 G_L + (x y^-h) G_R, H_hat = x H_L + x^-1 H_R (:187-204) become updates of the coefficient vectors
+__global__ __launch_bounds__(PV_T) void k_pw_fold(int nm, int n, int j, const uint8_t* __restrict__ tapes, size_t tape_len,
+                                                  const uint8_t* __restrict__ xj_be, const fqm* __restrict__ yp, const fqm* __restrict__ yinv,
+                                                  fqm* __restrict__ a, fqm* __restrict__ b, fqm* __restrict__ cG, fqm* __restrict__ cH,
+                                                  fqm* __restrict__ alpha_hat) {
+    __shared__ fqm xs[3];
+    const size_t pr = blockIdx.x;
+    const int h = n / 2;
+    if (threadIdx.x == 0) {
+        const fqm x = pv_be(xj_be + 32 * pr), xi = fqm_inv_var(x);  // (x = 0 is refused by the host before this launch)
+        xs[0] = x;
+        xs[1] = xi;
+        xs[2] = fqm_mul(x, pv_pow(yinv[pr], (uint32_t)h));
+        const uint8_t* tp = tapes + pr * tape_len;
+        const fqm xsq = fqm_mul(x, x), xisq = fqm_mul(xi, xi);
+        alpha_hat[pr] = fqm_add(alpha_hat[pr], fqm_add(fqm_mul(xsq, pv_be(tp + 32 * (size_t)TW_DL(j))), fqm_mul(xisq, pv_be(tp + 32 * (size_t)TW_DR(j)))));
+    }
+    __syncthreads();
+    const fqm x = xs[0], xi = xs[1], xyn = xs[2], yn = yp[pr * nm + h - 1];
+    fqm* A = a + pr * nm;
+    fqm* B = b + pr * nm;
+    for (int i = threadIdx.x; i < h; i += (int)blockDim.x) {  // lane i reads and writes only its own pair of slots
+        const fqm an = fqm_add(fqm_mul(A[i], x), fqm_mul(fqm_mul(yn, A[h + i]), xi));
+        const fqm bn = fqm_add(fqm_mul(B[h + i], x), fqm_mul(B[i], xi));
+        A[i] = an;
+        B[i] = bn;
+    }
+    for (int t = threadIdx.x; t < nm; t += (int)blockDim.x) {
+        const bool lower = (t & (n - 1)) < h;
+        cG[pr * nm + t] = fqm_mul(cG[pr * nm + t], lower ? xi : xyn);
+        cH[pr * nm + t] = fqm_mul(cH[pr * nm + t], lower ? x : xi);
+    }
+}
+
+// A' = r G_1 + s H_1 + (r y b + s y a) g + delta h (:222-232) and B' = r y s g + eta h (:235-239), G_1 / H_1 through the
+// coefficient vectors: (2 nm + 2) W and 2 W entries
+__global__ __launch_bounds__(PV_T) void k_pw_last(int nm, int k, int c, int W, const uint8_t* __restrict__ tapes, size_t tape_len,
+                                                  const uint8_t* __restrict__ yz_be, const fqm* __restrict__ a, const fqm* __restrict__ b,
+                                                  const fqm* __restrict__ cG, const fqm* __restrict__ cH, pv_ent* __restrict__ ent, size_t stride) {
+    const size_t pr = blockIdx.x;
+    const uint8_t* tp = tapes + pr * tape_len;
+    const fqm r = pv_be(tp + 32 * (size_t)TW_R(k)), sv = pv_be(tp + 32 * (size_t)TW_S(k));
+    pv_ent* eA = ent + (2 * pr) * stride;
+    pv_ent* eB = ent + (2 * pr + 1) * stride;
+    for (int t = threadIdx.x; t < nm; t += (int)blockDim.x) {
+        pv_digits(fqm_mul(r, cG[pr * nm + t]), c, W, t, eA + (size_t)t * W);
+        pv_digits(fqm_mul(sv, cH[pr * nm + t]), c, W, nm + t, eA + (size_t)(nm + t) * W);
+    }
+    if (threadIdx.x == 0) {
+        const fqm y = pv_be(yz_be + 64 * pr), a0 = a[pr * nm], b0 = b[pr * nm];
+        const fqm sG = fqm_add(fqm_mul(fqm_mul(a0, sv), y), fqm_mul(fqm_mul(b0, r), y));
+        pv_digits(sG, c, W, 2 * nm, eA + (size_t)(2 * nm) * W);
+        pv_digits(pv_be(tp + 32 * (size_t)TW_DELTA(k)), c, W, 2 * nm + 1, eA + (size_t)(2 * nm + 1) * W);
+        pv_digits(fqm_mul(y, fqm_mul(r, sv)), c, W, 2 * nm, eB);
+        pv_digits(pv_be(tp + 32 * (size_t)TW_ETA(k)), c, W, 2 * nm + 1, eB + W);
+    }
+}
+
+// r' = r + a e, s' = s + b e, delta' = eta + delta e + alpha e^2 (:245-256) -> [N][96] big-endian
+__global__ void k_pw_finish(size_t nproofs, int nm, int k, const uint8_t* __restrict__ tapes, size_t tape_len, const uint8_t* __restrict__ e_be,
+                            const fqm* __restrict__ a, const fqm* __restrict__ b, const fqm* __restrict__ alpha_hat, uint8_t* __restrict__ out_be) {
+    const size_t pr = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pr >= nproofs) return;
+    const uint8_t* tp = tapes + pr * tape_len;
+    const fqm e = pv_be(e_be + 32 * pr);
+    const fqm r = pv_be(tp + 32 * (size_t)TW_R(k)), sv = pv_be(tp + 32 * (size_t)TW_S(k));
+    const fqm delta = pv_be(tp + 32 * (size_t)TW_DELTA(k)), eta = pv_be(tp + 32 * (size_t)TW_ETA(k));
+    fq_to_be(out_be + 96 * pr, fqm_to_fq(fqm_add(r, fqm_mul(a[pr * nm], e))));
+    fq_to_be(out_be + 96 * pr + 32, fqm_to_fq(fqm_add(sv, fqm_mul(b[pr * nm], e))));
+    fq_to_be(out_be + 96 * pr + 64, fqm_to_fq(fqm_add(eta, fqm_add(fqm_mul(delta, e), fqm_mul(alpha_hat[pr], fqm_mul(e, e))))));
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------------
@@ -359,16 +549,26 @@ hipError_t launch_pv_round(size_t nproofs, int nm, int n, int c, int W, const ui
     hipLaunchKernelGGL(k_pv_round, dim3((unsigned)nproofs), dim3(pv_lanes(nm)), 0, st, nm, n, c, W, xu_be, a, b, cG, cH, ent, stride);
     return hipGetLastError();
 }
-// njobs jobs of cnt0 (even) / cnt1 (odd) entries; lanes per job so that the launch has about four waves per SIMD
-hipError_t launch_pv_msm(size_t njobs, const affine_mem* table, int c, const pv_ent* ent, size_t stride, int cnt0, int cnt1, xyzz* out,
-                         hipStream_t st) {
+// njobs jobs of cnt0 (even) / cnt1 (odd) entries -> out[njobs]; lanes per job (and, past 256 lanes, workgroups per job) so that
+// the launch has about four waves per SIMD.  `partial` holds njobs * PV_MSM_MAXPARTS sums.
+hipError_t launch_pv_msm(size_t njobs, const affine_mem* table, int c, const pv_ent* ent, size_t stride, int cnt0, int cnt1, xyzz* partial,
+                         xyzz* out, hipStream_t st) {
     if (njobs == 0) return hipSuccess;
     if (cnt0 < 1 || cnt1 < 1 || (size_t)cnt0 > stride || (size_t)cnt1 > stride) return hipErrorInvalidValue;
-    int tp = 64;
-    while (tp > 4 && (njobs * (size_t)tp > ((size_t)1 << 18) || tp * 4 > (cnt0 > cnt1 ? cnt0 : cnt1))) tp >>= 1;
-    const unsigned blocks = (unsigned)((njobs + (256 / tp) - 1) / (256 / tp));
-#define PV_MSM(TP) hipLaunchKernelGGL((k_pv_msm<TP>), dim3(blocks), dim3(256), 0, st, njobs, table, c, ent, stride, cnt0, cnt1, out)
-    if (tp == 64)
+    const int cmax = cnt0 > cnt1 ? cnt0 : cnt1;
+    int tp = 256, parts = 1;
+    while (tp > 4 && (njobs * (size_t)tp > ((size_t)1 << 18) || tp * 4 > cmax)) tp >>= 1;
+    if (tp == 256)
+        while (parts < PV_MSM_MAXPARTS && njobs * (size_t)(256 * parts * 2) <= ((size_t)1 << 18) && 256 * parts * 2 * 8 <= cmax) parts *= 2;
+    const size_t units = njobs * (size_t)parts;
+    const unsigned blocks = (unsigned)((units + (256 / tp) - 1) / (256 / tp));
+    xyzz* dst = parts > 1 ? partial : out;
+#define PV_MSM(TP) hipLaunchKernelGGL((k_pv_msm<TP>), dim3(blocks), dim3(256), 0, st, njobs, table, c, ent, stride, cnt0, cnt1, parts, dst)
+    if (tp == 256)
+        PV_MSM(256);
+    else if (tp == 128)
+        PV_MSM(128);
+    else if (tp == 64)
         PV_MSM(64);
     else if (tp == 32)
         PV_MSM(32);
@@ -379,6 +579,7 @@ hipError_t launch_pv_msm(size_t njobs, const affine_mem* table, int c, const pv_
     else
         PV_MSM(4);
 #undef PV_MSM
+    if (parts > 1) hipLaunchKernelGGL(k_pv_msm_combine, dim3((unsigned)((njobs + 63) / 64)), dim3(64), 0, st, njobs, parts, partial, out);
     return hipGetLastError();
 }
 hipError_t launch_pv_fold(size_t nproofs, int nm, int n, const uint8_t* xj_be, fqm* a, fqm* b, fqm* cG, fqm* cH, hipStream_t st) {
@@ -387,6 +588,39 @@ hipError_t launch_pv_fold(size_t nproofs, int nm, int n, const uint8_t* xj_be, f
 }
 hipError_t launch_pv_final(size_t nproofs, int nm, const fqm* a, const fqm* b, uint8_t* out_be, hipStream_t st) {
     hipLaunchKernelGGL(k_pv_final, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, nproofs, nm, a, b, out_be);
+    return hipGetLastError();
+}
+
+hipError_t launch_pw_init(size_t nproofs, int nm, int c, int W, const uint8_t* tapes, size_t tape_len, const uint8_t* bits, pv_ent* ent,
+                          size_t stride, hipStream_t st) {
+    hipLaunchKernelGGL(k_pw_init, dim3((unsigned)nproofs), dim3(pv_lanes(nm)), 0, st, nm, c, W, tapes, tape_len, bits, ent, stride);
+    return hipGetLastError();
+}
+hipError_t launch_pw_setup(size_t nproofs, int n_bits, int m, const uint8_t* tapes, size_t tape_len, const uint8_t* yz_be,
+                           const uint8_t* blindings_be, const uint8_t* bits, fqm* yp, fqm* a, fqm* b, fqm* cG, fqm* cH, fqm* alpha_hat, fqm* yinv,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(k_pw_setup, dim3((unsigned)nproofs), dim3(pv_lanes(n_bits * m)), 0, st, n_bits, m, tapes, tape_len, yz_be, blindings_be, bits, yp, a,
+                       b, cG, cH, alpha_hat, yinv);
+    return hipGetLastError();
+}
+hipError_t launch_pw_round(size_t nproofs, int nm, int n, int j, int c, int W, const uint8_t* tapes, size_t tape_len, const fqm* yp, const fqm* yinv,
+                           const fqm* a, const fqm* b, const fqm* cG, const fqm* cH, pv_ent* ent, size_t stride, hipStream_t st) {
+    hipLaunchKernelGGL(k_pw_round, dim3((unsigned)nproofs), dim3(pv_lanes(nm)), 0, st, nm, n, j, c, W, tapes, tape_len, yp, yinv, a, b, cG, cH, ent, stride);
+    return hipGetLastError();
+}
+hipError_t launch_pw_fold(size_t nproofs, int nm, int n, int j, const uint8_t* tapes, size_t tape_len, const uint8_t* xj_be, const fqm* yp,
+                          const fqm* yinv, fqm* a, fqm* b, fqm* cG, fqm* cH, fqm* alpha_hat, hipStream_t st) {
+    hipLaunchKernelGGL(k_pw_fold, dim3((unsigned)nproofs), dim3(pv_lanes(nm)), 0, st, nm, n, j, tapes, tape_len, xj_be, yp, yinv, a, b, cG, cH, alpha_hat);
+    return hipGetLastError();
+}
+hipError_t launch_pw_last(size_t nproofs, int nm, int k, int c, int W, const uint8_t* tapes, size_t tape_len, const uint8_t* yz_be, const fqm* a,
+                          const fqm* b, const fqm* cG, const fqm* cH, pv_ent* ent, size_t stride, hipStream_t st) {
+    hipLaunchKernelGGL(k_pw_last, dim3((unsigned)nproofs), dim3(pv_lanes(nm)), 0, st, nm, k, c, W, tapes, tape_len, yz_be, a, b, cG, cH, ent, stride);
+    return hipGetLastError();
+}
+hipError_t launch_pw_finish(size_t nproofs, int nm, int k, const uint8_t* tapes, size_t tape_len, const uint8_t* e_be, const fqm* a, const fqm* b,
+                            const fqm* alpha_hat, uint8_t* out_be, hipStream_t st) {
+    hipLaunchKernelGGL(k_pw_finish, dim3((unsigned)((nproofs + 63) / 64)), dim3(64), 0, st, nproofs, nm, k, tapes, tape_len, e_be, a, b, alpha_hat, out_be);
     return hipGetLastError();
 }
 

@@ -2,7 +2,7 @@
 import collections, sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 rows = list(c.execute("select name,start,end from kernels order by start"))
-i0 = [i for i, r in enumerate(rows) if "k_pv_init" in r[0]][-1]
+i0 = [i for i, r in enumerate(rows) if "k_pv_init" in r[0] or "k_pw_init" in r[0]][-1]
 t0 = rows[i0][1]
 agg = collections.OrderedDict()
 for n, s, e in rows[i0:]:

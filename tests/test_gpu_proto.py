@@ -201,9 +201,10 @@ def test_generate_bases_on_device_matches_host_and_oracle(ctx, kind, seed, n, m)
 
 @pytest.mark.parametrize("kind,n,m,count", [(0, 64, 1, 40), (0, 16, 2, 7), (1, 64, 1, 33), (1, 8, 4, 5), (0, 64, 1, 150)])
 def test_prove_batch_matches_single_proofs(ctx, kind, n, m, count):
-    """bp_rangeproof_prove_batch / bp_wip_rangeproof_prove_batch (one GPU launch per protocol step for all proofs, the
-    scalar work of every proof on its own host thread): every proof byte-identical to the single-proof call on the same
-    inputs (whose bytes the tests above pin to the oracle), more proofs than one 128-thread chunk, and all of them verify."""
+    """bp_rangeproof_prove_batch / bp_wip_rangeproof_prove_batch (the device batch provers: per-proof vectors as kernels over
+    [proof][i], one table-MSM launch per protocol step for all proofs, the transcript on the host): every proof byte-identical
+    to the single-proof call on the same inputs (whose bytes the tests above pin to the oracle), batches that span both
+    lanes, and all of them verify."""
     from oracle import tape
     g, h, G, H = bpa.generate_bases(kind, bpa.KZEN_SEED, n, m)
     gens = bpa.Gens(ctx, g, h, G, H, 8)
