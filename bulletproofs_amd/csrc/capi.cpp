@@ -255,13 +255,11 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
             memset(ss, 0, sizeof(*ss));
             ctx->srt_streams = ss;
             HIPCHK(ctx->side_stream(&ss->st2), "hipStreamCreate");  // the context's side stream (ctx.h)
-            {   // the bucket reductions are the critical path beside the next group's accumulation: highest stream priority
-                int plo = 0, phi = 0;
-                (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
-                int prio = phi;
-                if (const char* e = bp_tune("BP_MSM_PRIO")) prio = atoi(e) ? phi : 0;  // TUNING
-                HIPCHK(hipStreamCreateWithPriority(&ss->st3, hipStreamNonBlocking, prio), "hipStreamCreate");
-            }
+            // An ordinary stream, NOT a high-priority one: a priority stream is a hardware queue of its own beside the process's four,
+            // and with one more stream in the process (a second context, a prover lane) the cross-queue waits of launch_msm_sorted
+            // never completed on this system - the call hung (scripts/experiments/prove_then_msm.py reproduces it with the
+            // priority put back).  Its measured gain was nil (2^20 points 2.15 ms either way).
+            HIPCHK(hipStreamCreateWithFlags(&ss->st3, hipStreamNonBlocking), "hipStreamCreate");
             ss->st4 = ss->st2;  // a stream of its own shared st3's hardware queue (4 per process) and serialised the two
             for (int g = 0; g < SortedStreams::kMaxGroups; g++) {
                 HIPCHK(hipEventCreateWithFlags(&ss->ev_acc[g], hipEventDisableTiming), "hipEventCreate");
@@ -433,7 +431,7 @@ void bp_ctx_destroy(bp_ctx* ctx) {
     if (ctx->v_ev_side) (void)hipEventDestroy(ctx->v_ev_side);
     if (ctx->v_ev_fork) (void)hipEventDestroy(ctx->v_ev_fork);
     if (ctx->v_ev_join) (void)hipEventDestroy(ctx->v_ev_join);
-    (void)hipStreamDestroy(ctx->stream);
+    if (!ctx->stream_borrowed) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 

@@ -72,7 +72,8 @@ struct bp_ctx {
             v_side_pending = false;
         }
     }
-    std::vector<bp_ctx*> prove_lanes;  // batch provers: further contexts, one per rendezvous group in flight (proto.cpp), owned by this one
+    std::vector<bp_ctx*> prove_lanes;  // batch provers: further contexts, one per lane in flight (proto.cpp), owned by this one
+    bool stream_borrowed = false;      // a prover lane whose `stream` is its owner's side stream (not destroyed with the lane)
     int proto_path = 0;  // protocol layer: 0 = every generator MSM from the fixed-base table, 1 = reference-structured (bp_proto_set_path)
     // optional per-kernel timing (bp_profile_*): HIP events on this context's stream
     bool profiling = false;

@@ -2021,11 +2021,25 @@ static int prove_batch_impl(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m,
     }
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     // Lane l > 0 owns a context of its own (stream, pinned staging, workspaces; created once, kept by `ctx`); lane 0 is `ctx`.
+    // The first of them runs on the context's side stream instead of a stream of its own: a process has four hardware queues,
+    // and every further stream lands on an occupied one (ctx.h).  (The side stream's other users - the verifier's side lane, the
+    // sorted MSM - are entry points of this context and cannot run during this call.)
     auto ensure_lanes = [&](size_t lanes) -> int {
         while (ctx->prove_lanes.size() + 1 < lanes) {
             bp_ctx* sub = nullptr;
             int rc = bp_ctx_create(ctx->device, &sub);
             if (rc != BP_OK) return rc;
+            if (ctx->prove_lanes.empty()) {
+                hipStream_t side = nullptr;
+                if (ctx->side_stream(&side) == hipSuccess) {
+                    (void)hipStreamSynchronize(sub->stream);
+                    (void)hipStreamDestroy(sub->stream);
+                    sub->stream = side;
+                    sub->stream_borrowed = true;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
             ctx->prove_lanes.push_back(sub);
         }
         return BP_OK;

@@ -265,9 +265,12 @@ int bp_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint
  * `RangeProofWIP::prove` (range_proof_wip.rs:101-274) for nproofs independent proofs over the same generators, each
  * byte-identical to the single-proof call on the same inputs.  Proof i uses secrets_be / blindings_be [i*m .. i*m+m)
  * (32 B each) and tapes[i*tape_len ..] (the single-proof tape layout); proofs_out receives nproofs * proof_len bytes
- * (proof_len = 292 + 66 k, 195 + 66 k for Bulletproofs+).  The per-proof scalar work runs on host threads (up to 128
- * proofs in flight) and every protocol step of all of them is ONE GPU launch.  status (nullable) receives the per-proof
- * return codes; the call returns the first failing one.  Needs the fixed-base table path (bp_proto_set_path 0). */
+ * (proof_len = 292 + 66 k, 195 + 66 k for Bulletproofs+).  The per-proof vectors (range_proof.rs:131-212,
+ * inner_product.rs:64-155, weighted_inner_product.rs:71-204) are kernels over [proof][i] on the GPU and every protocol
+ * step of all proofs is ONE table-MSM launch; the host keeps only the Fiat-Shamir transcript and the proof encoding
+ * (generator sets beyond 4096 terms: one host thread per proof around the same launches).  status (nullable) receives
+ * the per-proof return codes (BP_EINVAL: tape scalar zero or not canonical, a zero challenge, an identity point); the
+ * call returns the first failing one.  Needs the fixed-base table path (bp_proto_set_path 0).  Synchronous. */
 int bp_rangeproof_prove_batch(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, size_t nproofs, const uint8_t* secrets_be,
                               const uint8_t* blindings_be, const uint8_t* tapes, size_t tape_len, uint8_t* proofs_out, size_t proof_len,
                               int* status);

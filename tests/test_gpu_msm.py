@@ -188,6 +188,41 @@ def test_msm_grouped_pipeline_skewed_scalars(ctx, oracle_c):
             ctx.set_msm_pipeline(0)
 
 
+@pytest.mark.timeout(150)
+def test_msm_grouped_pipeline_with_other_streams_in_the_process(ctx, oracle_c):
+    """The multi-stream pipeline next to other users of the process's four hardware queues: a second context that has
+    run work, and the batch prover's lane (which runs on the context's side stream).  Regression test: with a
+    high-priority reduction stream the cross-stream waits of the pipeline never completed once any further stream
+    existed, and the call hung (scripts/experiments/prove_then_msm.py)."""
+    import bulletproofs_amd as bpa
+    from oracle import tape
+    rng = random.Random(777)
+    n = 70000
+    rs = [rng.randrange(1, ec.Q) for _ in range(64)]
+    base = oracle_c.mul_batch([ec.G] * 64, rs)
+    idx = [rng.randrange(64) for _ in range(n)]
+    ks = [rng.randrange(ec.Q) for _ in range(n)]
+    pb, sb = _pack([base[i] for i in idx], ks)
+    want = ec.enc64(oracle_c.mul(ec.G, sum(ks[i] * rs[idx[i]] for i in range(n)) % ec.Q))
+    other = bpa.Context(0)
+    g, h, G, H = bpa.generate_bases(0, bpa.KZEN_SEED, 8, 1)
+    gens = bpa.Gens(ctx, g, h, G, H, 4)
+    try:
+        assert len(other.fixed_base_mul_batch((7).to_bytes(32, "big") * 64)) == 64 * 64
+        count, ntape = 1100, 2 + 2 * 8 + 2  # more than one chunk: both prover lanes run
+        tb = [tape.make_tape_bytes("msm-lanes-%d" % i, 1 + ntape) for i in range(count)]
+        proofs = ctx.rangeproof_prove_batch(gens, 8, 1, b"".join((i % 256).to_bytes(32, "big") for i in range(count)),
+                                            b"".join(t[:32] for t in tb), b"".join(t[32:] for t in tb), 32 * ntape)
+        assert len(proofs) == count
+        for _ in range(2):
+            assert ctx.msm(pb, sb, None) == want
+        assert other.msm(pb, sb, None) == want  # and the other context's own pipeline (a seventh stream)
+        assert ctx.msm(pb, sb, None) == want
+    finally:
+        gens.close()
+        other.close()
+
+
 def test_msm_full_size_2pow20(ctx, oracle_c):
     """BASELINE.json configs[4] size (2^20 terms): sum k_i (r_i G) == (sum k_i r_i) G with 2^20 distinct
     points r_i G made on the GPU (fixed-base batch) and independent 256-bit scalars."""
