@@ -1072,7 +1072,7 @@ def main():
                         "RangeProof::aggregated_verify, n=64 m=16", fixture=("bp_c2_n64_m16.json", None), nb=512)
     if world == 1 and not args.no_c4:
         c4 = side_batch(1, 64, max(64, P // 64), "bp_wip_rangeproof_verify_batch_device at BASELINE.json configs[3]'s shape: "
-                        "RangeProofWIP::aggregated_verify (range_proof_wip.rs:388-609), n=64 m=64", fixture=("bpplus_c4_n64_m64.json", None), nb=32)
+                        "RangeProofWIP::aggregated_verify (range_proof_wip.rs:388-609), n=64 m=64", fixture=("bpplus_c4_n64_m64.json", None), nb=256)
     if world == 1 and not args.no_msm:
         msm = msm_side(ctx, dev, args.msm_log2, max(args.steps, 10))
 

@@ -19,6 +19,14 @@ timeout -k 10 300 python3 bench.py --workload prove --steps 8 > $O/prove_latency
 timeout -k 10 300 python3 scripts/experiments/bigtable_test.py 4096 12,14,16 > $O/bigtable.txt 2> $O/bigtable.err
 timeout -k 10 120 ./bench_micro/ecops > $O/ecops.jsonl 2> $O/ecops.err
 timeout -k 10 120 ./bench_micro/peak_mad32 > $O/peak_mad32.jsonl 2> $O/peak.err
+# round 3: small-batch timeline and lane sweep, batch-prover rates and kernel breakdowns, raw-MSM sizes and timeline
+bash scripts/small_batch_timeline.sh 512 > $O/small_batch_512.txt 2>&1
+timeout -k 10 200 python3 -u scripts/experiments/slice8_test.py > $O/small_batch_lanes.txt 2> $O/slice8.err
+for w in "c1 4096" "c1 16384" "c2 512" "c2 2048" "c4 256"; do timeout -k 10 200 python3 -u scripts/experiments/prove_batch_sweep.py $w >> $O/prove_batch.txt 2>> $O/prove_batch.err; done
+LANES=1 bash scripts/r3_pvprof.sh "c1 2048" "c2 512" "c4 256" > $O/prove_batch_profiled.txt 2>&1
+for w in c1 c2 c4; do echo "== $w (kernels from the last chunk's first launch on; two lanes interleave)" >> $O/prove_batch_kernels.txt; python3 scripts/pvprof_report.py gpurun_out/r3_pv_prof_$w/pv_results.db >> $O/prove_batch_kernels.txt; rm -rf gpurun_out/r3_pv_prof_$w; done
+bash scripts/r3_msm.sh notests "16 18 20 22" "default" > $O/msm_sizes_timeline.txt 2>&1
+cd $GRAFT_REPO_ROOT
 for d in kt kt_serial pmc_rd pmc_wr pmc_valu msm_kt msm_pmc_rd msm_pmc_wr; do f=$(ls $O/$d/*_results.db); m=pmc; case $d in kt|kt_serial|msm_kt) m=stats;; esac; python3 profiles/summarize.py $m $f $O/$d.csv; rm -rf $O/$d; done  # raw rocprof databases stay on the box (gpurun merges back <= 64 MiB)
 du -sh $O
 echo PROFILES_OK
