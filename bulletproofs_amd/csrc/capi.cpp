@@ -142,7 +142,7 @@ SortedPlan plan_msm_sorted(size_t n2, int forced_c) {
 // exposed tail is one window's bucket reduction and a single addition (its Horner step is done by k_srt_dbl while the
 // window still accumulates) - 5,3,1 at W = 9: 2.38-2.51 ms against 2.53-2.65 for 5,4 and 2.9 for 4,2,2,1.
 // BP_MSM_GROUPS="3,3,2,1" overrides (tuning).
-static int plan_window_groups(int W, int* gsz) {
+static int plan_window_groups(int W, int* gsz, size_t n2) {
     int ng = 0;
     if (const char* e = bp_tune("BP_MSM_GROUPS")) {
         int left = W;
@@ -163,6 +163,14 @@ static int plan_window_groups(int W, int* gsz) {
     if (W < 6) {
         gsz[0] = W - W / 2;
         gsz[1] = W / 2;
+        return 2;
+    }
+    // from 2^21 points an accumulation launch is long enough that a middle group only adds a reduction beside the last window:
+    // W - 1 windows, then one (2^22 points, W = 9: 8,1 6.87 ms, 4,4,1 6.97, 6,2,1 7.30, 5,3,1 7.55; at 2^20 all of these are within
+    // 2 % of 2.17 ms - gpurun_out/r3_groups.log)
+    if (n2 >= ((size_t)1 << 22)) {
+        gsz[0] = W - 1;
+        gsz[1] = 1;
         return 2;
     }
     gsz[0] = ((W - 1) * 5 + 7) / 8;
@@ -249,7 +257,11 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
         // multi-GPU partials)
         int gsz[SortedStreams::kMaxGroups];
         int ng = 0;
-        if (!want_c && n2 >= ((size_t)1 << 17) && ctx->msm_pipeline == 0) ng = plan_window_groups(W, gsz);
+        // from 2^19 points: below that one group on one stream is as fast or faster (2^16 / 2^17 / 2^18 points: 0.69 / 0.93 / 1.12 ms
+        // against 0.75 / 0.97 / 1.16 in groups; 2^19: 1.59 against 1.40; gpurun_out/r3_mid_msm.log).  bp_msm_set_pipeline(ctx, 2)
+        // takes the groups from 2^16 points on (tests).
+        const size_t group_min = ctx->msm_pipeline == 2 ? ((size_t)1 << 17) : ((size_t)1 << 20);
+        if (!want_c && n2 >= group_min && ctx->msm_pipeline != 1) ng = plan_window_groups(W, gsz, n2);
         if (ng > 1 && !ctx->srt_streams) {
             SortedStreams* ss = new SortedStreams();
             memset(ss, 0, sizeof(*ss));
@@ -442,7 +454,7 @@ void bp_msm_set_path(bp_ctx* ctx, int path) {
     if (ctx) ctx->msm_path = (path >= 1 && path <= 3) ? path : 0;
 }
 void bp_msm_set_pipeline(bp_ctx* ctx, int mode) {
-    if (ctx) ctx->msm_pipeline = mode == 1 ? 1 : 0;
+    if (ctx) ctx->msm_pipeline = (mode == 1 || mode == 2) ? mode : 0;
 }
 void bp_proto_set_path(bp_ctx* ctx, int path) {
     if (ctx) ctx->proto_path = path == 1 ? 1 : 0;

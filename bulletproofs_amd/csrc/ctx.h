@@ -41,7 +41,7 @@ struct bp_ctx {
     int forced_c = 0;
     int ncu = 0;  // compute units of the device (window-group launches are sized per CU)
     int msm_path = 0;  // 0 auto, 1 LDS slice path, 2 sorted path (bp_msm_set_path)
-    int msm_pipeline = 0;  // 0 = window groups on side streams (lowest latency of one call), 1 = one group (bp_msm_set_pipeline)
+    int msm_pipeline = 0;  // 0 = window groups on side streams from 2^19 points (lowest latency of one call), 1 = one group, 2 = groups from 2^16 points (bp_msm_set_pipeline)
     int verify_lanes = 0;
     // Batch verifier, asynchronous device entry points (bp_verify_set_overlap, verify_api.cpp): successive calls alternate
     // between ctx->stream with the context's workspaces and a side lane (own stream, own workspaces `vws`), so that two

@@ -793,17 +793,18 @@ static void srt_acc_windows(const affine_mem* pts, const affine_mem* lam, size_t
 static hipError_t srt_reduce_windows(const SortedPlan& pl, const SortedBufs& b, int w0, int nw, int L, xyzz* wsum, hipStream_t st, bool lat) {
     const int NB = pl.NB;
     const int nout = (1 << pl.lo_bits) + (NB >> pl.lo_bits);
-    // Logical lanes per output: 64.  Exposed latency (the last window group; one group only): QUADS that share every
-    // addition (ecq.h), 256-lane workgroups = one wave per SIMD of a CU (rowcol2 for one window 142 -> 58 us).  Beside an
-    // accumulation, where throughput counts: single lanes, one wave per output (quads there, 16 or 32 or 64 per output,
-    // measured 2.22-2.33 ms per 2^20 MSM against 2.15: a quad spends four lanes on 2.2 times the speed; gpurun_out/r3_j.log).
-    int T = lat ? 64 : 0;
-    if (const char* e = bp_tune("BP_MSM_RC_T")) {  // TUNING: "<latency T>,<throughput T>", 0 = single lanes (T = 64)
+    // 64 QUADS per output that share every addition (ecq.h), 256-lane workgroups (rowcol2 for one window 142 -> 58 us).  For the
+    // groups that reduce beside an accumulation single lanes looked better at first (gpurun_out/r3_j.log, with a high-priority
+    // reduction stream); with ordinary streams quads win at every size: 2^19 points 1.51 -> 1.41 ms, 2^20 2.08 -> 2.05, 2^22 equal;
+    // 16 or 32 quads per output are slower (2^20: 2.22 ms) - gpurun_out/r3_mid_msm2.log.
+    (void)lat;
+    int T = 64;
+    if (const char* e = bp_tune("BP_MSM_RC_T")) {  // TUNING: "<last group's T>,<earlier groups' T>", 0 = single lanes
         int a = atoi(e), b2 = a;
         if (const char* cpos = strchr(e, ',')) b2 = atoi(cpos + 1);
         T = lat ? a : b2;
     }
-    if (T == 16 || T == 32 || T == 64 || T == 128)
+    if (T == 16 || T == 32 || T == 64)
         hipLaunchKernelGGL(k_srt_rowcol2<4>, dim3((unsigned)nout, (unsigned)nw), dim3((unsigned)(4 * T)), (size_t)T * sizeof(xyzz), st, b.bstart, b.Bk, b.Pseg,
                            NB, L, pl.pstride, pl.lo_bits, w0, b.RC);
     else

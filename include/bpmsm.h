@@ -98,10 +98,11 @@ void bp_msm_set_window(bp_ctx* ctx, int c);
  * path (large n), 3 = sorted path with its two-pass bucket sort at any size (automatic from 2^14 terms).
  * All compute the same sum; results are identical. */
 void bp_msm_set_path(bp_ctx* ctx, int path);
-/* Large MSMs (>= 2^16 terms) run their windows in groups, each group's latency-bound tail (bucket reduction, Horner
+/* Large MSMs (>= 2^19 terms) run their windows in groups, each group's latency-bound tail (bucket reduction, Horner
  * chain) on side streams beside the next group's accumulation: mode 0 (default), the lowest latency of ONE call.
  * mode 1 = one group, no side streams: less total GPU work, the better choice when several contexts keep the GPU
- * busy at once (their tails overlap each other anyway).  Results are identical. */
+ * busy at once (their tails overlap each other anyway).  mode 2 = groups from 2^16 terms on (where one group is
+ * faster: for tests of the grouped pipeline at small sizes).  Results are identical. */
 void bp_msm_set_pipeline(bp_ctx* ctx, int mode);
 
 /* Testing / tuning knob for the protocol entry points (bp_rangeproof_prove / _verify, bp_wip_*):

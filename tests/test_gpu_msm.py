@@ -154,7 +154,7 @@ def test_msm_linearity_large(ctx, oracle_c):
 
 
 def test_msm_grouped_pipeline_skewed_scalars(ctx, oracle_c):
-    """The grouped, multi-stream pipeline of the sorted path (n >= 2^16: window groups top-down, bucket reduction
+    """The grouped, multi-stream pipeline of the sorted path (automatic from 2^19 points, forced here: window groups top-down, bucket reduction
     and Horner chain beside the next group's accumulation, per-window bucket grid) on scalar distributions that
     leave windows empty, fill single buckets, or fill only the lowest buckets of a window:
     sum k_i (r_j G) == (sum k_i r_j) G."""
@@ -176,6 +176,8 @@ def test_msm_grouped_pipeline_skewed_scalars(ctx, oracle_c):
         pb, sb = _pack(pts, ks)
         want_scalar = sum(ks[i] * rs[idx[i]] for i in range(n)) % ec.Q
         want = ec.enc64(oracle_c.mul(ec.G, want_scalar)) if want_scalar else bytes(64)
+        assert ctx.msm(pb, sb, None) == want, name  # automatic: one group at this size
+        ctx.set_msm_pipeline(2)  # the window groups (automatic from 2^19 points)
         assert ctx.msm(pb, sb, None) == want, name
         if name in ("pm1", "mixed"):  # with an init point: the final kernel adds S_0, the doubled upper combination AND init
             init = oracle_c.mul(ec.G, 0xC0FFEE)
@@ -214,11 +216,14 @@ def test_msm_grouped_pipeline_with_other_streams_in_the_process(ctx, oracle_c):
         proofs = ctx.rangeproof_prove_batch(gens, 8, 1, b"".join((i % 256).to_bytes(32, "big") for i in range(count)),
                                             b"".join(t[:32] for t in tb), b"".join(t[32:] for t in tb), 32 * ntape)
         assert len(proofs) == count
+        ctx.set_msm_pipeline(2)  # the window groups at this size
+        other.set_msm_pipeline(2)
         for _ in range(2):
             assert ctx.msm(pb, sb, None) == want
         assert other.msm(pb, sb, None) == want  # and the other context's own pipeline (a seventh stream)
         assert ctx.msm(pb, sb, None) == want
     finally:
+        ctx.set_msm_pipeline(0)
         gens.close()
         other.close()
 
