@@ -16,6 +16,23 @@ struct fq {
     uint32_t v[8];
 };
 
+// bits [bit, bit + 32) of the 256-bit value k[0..8) (zero above bit 255), 0 <= bit < 256.  The limb index is a run-time value:
+// indexing k[limb] directly makes the compiler keep the eight words in scratch memory and every window digit two scratch loads
+// (a 36-byte private segment in every digit kernel; k_pw_round spent 0.6 ms per launch there); sixteen selects keep them in
+// registers.
+BP_HD uint32_t fq_bits32(const uint32_t k[8], int bit) {
+    const int limb = bit >> 5, sh = bit & 31;
+    uint32_t lo = 0, hi = 0;
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+#endif
+    for (int i = 0; i < 8; i++) {
+        lo = (limb == i) ? k[i] : lo;
+        hi = (limb + 1 == i) ? k[i] : hi;
+    }
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+}
+
 #define BP_Q_LIMBS {0xd0364141u, 0xbfd25e8cu, 0xaf48a03bu, 0xbaaedce6u, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu}
 #define BP_Q_INV32 0x5588b13fu /* -q^-1 mod 2^32 */
 

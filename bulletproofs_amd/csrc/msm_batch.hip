@@ -39,10 +39,7 @@ __global__ void k_mb_digits(const uint8_t* __restrict__ scalars_be, size_t total
         int bit = w * c;
         uint32_t v = 0;
         if (bit < 256) {
-            int limb = bit >> 5, sh = bit & 31;
-            uint64_t two = k.v[limb];
-            if (limb + 1 < 8) two |= (uint64_t)k.v[limb + 1] << 32;
-            v = (uint32_t)(two >> sh) & mask;
+            v = fq_bits32(k.v, bit) & mask;
         }
         v += carry;
         int d;

@@ -63,10 +63,7 @@ __device__ __forceinline__ void recode_signed(const uint32_t k[8], int c, int W,
         int bit = w * c;
         uint32_t v = 0;
         if (bit < 256) {
-            int limb = bit >> 5, sh = bit & 31;
-            uint64_t two = k[limb];
-            if (limb + 1 < 8) two |= (uint64_t)k[limb + 1] << 32;
-            v = (uint32_t)(two >> sh) & mask;
+            v = fq_bits32(k, bit) & mask;
         }
         v += carry;
         int d;

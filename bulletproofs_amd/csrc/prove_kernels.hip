@@ -28,10 +28,7 @@ __device__ __forceinline__ void pv_store_digits(const fq& kk, int c, int W, int 
         const int bit = w * c;
         uint32_t v = 0;
         if (bit < 256) {
-            const int limb = bit >> 5, sh = bit & 31;
-            uint64_t two = kk.v[limb];
-            if (limb + 1 < 8) two |= (uint64_t)kk.v[limb + 1] << 32;
-            v = (uint32_t)(two >> sh) & mask;
+            v = fq_bits32(kk.v, bit) & mask;
         }
         v += carry;
         pv_ent e;

@@ -195,10 +195,7 @@ __device__ __forceinline__ int window_digit(const fq& kk, int c, int w, uint32_t
     int bit = w * c;
     uint32_t v = 0;
     if (bit < 256) {
-        int limb = bit >> 5, sh = bit & 31;
-        uint64_t two = kk.v[limb];
-        if (limb + 1 < 8) two |= (uint64_t)kk.v[limb + 1] << 32;
-        v = (uint32_t)(two >> sh) & mask;
+        v = fq_bits32(kk.v, bit) & mask;
     }
     v += carry;
     if (v > half) {
