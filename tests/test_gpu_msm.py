@@ -246,6 +246,25 @@ def test_msm_full_size_2pow20(ctx, oracle_c):
     assert got == ec.enc64(oracle_c.mul(ec.G, acc % ec.Q))
 
 
+def test_msm_2pow21_two_group_plan(ctx, oracle_c):
+    """From 2^21 terms the window groups are W - 1 + 1 (capi.cpp plan_window_groups): the same size-independent check as
+    above on 2^21 terms made of 2^16 distinct points (each used 32 times with independent scalars)."""
+    import numpy as np
+    n, nd = 1 << 21, 1 << 16
+    rng = np.random.default_rng(2121)
+    rb = rng.integers(0, 256, size=(nd, 32), dtype=np.uint8)
+    kb = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    rb[:, 0] &= 0x7F
+    base = ctx.fixed_base_mul_batch(rb.tobytes())
+    got = ctx.msm(base * (n // nd), kb.tobytes(), None)
+    rs = [int.from_bytes(rb[i].tobytes(), "big") for i in range(nd)]
+    kbb = kb.tobytes()
+    acc = 0
+    for i in range(n):
+        acc += rs[i % nd] * int.from_bytes(kbb[32 * i:32 * i + 32], "big")
+    assert got == ec.enc64(oracle_c.mul(ec.G, acc % ec.Q))
+
+
 def test_msm_batch_shared_generators(ctx, oracle_c):
     """bp_msm_batch: jobs sharing the generator prefix (fixed-base table) plus job-specific points.
     Checked term by term against the oracle fold idiom; includes a job without generator scalars, a job
