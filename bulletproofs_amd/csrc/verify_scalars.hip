@@ -672,24 +672,15 @@ hipError_t launch_bpv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, i
 #define PFW_SCALARS(k) (33 * (2 * (k) + 3))
 #define CH_E CH_X
 
-__global__ __launch_bounds__(64) void k_wipv_hash1(const uint8_t* __restrict__ proofs, size_t proof_len, int k, int m, int nm, size_t nproofs,
-                                                   const affine_mem* __restrict__ pts, const affine_mem* __restrict__ gens, fq* __restrict__ chal,
-                                                   int* __restrict__ bad) {
-    __shared__ __align__(4) uint8_t lds[64 * MSG_STRIDE];
-    const int jobs = k + 2;
-    size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (gid >= nproofs * jobs) return;
-    size_t pr = gid / jobs;
-    int job = (int)(gid % jobs);
-    if (bad[pr]) return;
-    uint8_t* buf = lds + threadIdx.x * MSG_STRIDE;
+__device__ __forceinline__ void wipv_hash1_job(size_t pr, int job, uint8_t* buf, const uint8_t* __restrict__ proofs, size_t proof_len, int k, int m,
+                                               int nm, const affine_mem* __restrict__ pts, const affine_mem* __restrict__ gens, fq* chal, int* badflag) {
     const int NPT = 3 + 2 * k + m;
     const affine_mem* P = pts + pr * NPT;
     int pos = 0;
     if (job == 0) {  // y = H(A)                                               range_proof_wip.rs:420
         const uint8_t* sc = proofs + pr * proof_len + PFW_SCALARS(k);
         // scalars in the proof must be canonical (< q), as curv's deserialisation yields
-        if (!(fq_be_is_canonical(sc) && fq_be_is_canonical(sc + 32) && fq_be_is_canonical(sc + 64))) atomicOr(&bad[pr], 1);
+        if (!(fq_be_is_canonical(sc) && fq_be_is_canonical(sc + 32) && fq_be_is_canonical(sc + 64))) atomicOr(badflag, 1);
         msg_put_point(buf, pos, P[1]);
         chal[pr * CH_COUNT(k) + CH_Y] = msg_result_scalar(buf, pos);
     } else if (job == 1) {  // e = H(a_tag, b_tag, g, h)                        :465-467
@@ -706,6 +697,17 @@ __global__ __launch_bounds__(64) void k_wipv_hash1(const uint8_t* __restrict__ p
         msg_put_point(buf, pos, gens[2 * nm + 1]);
         chal[pr * CH_COUNT(k) + CH_XJ + j] = msg_result_scalar(buf, pos);
     }
+}
+__global__ __launch_bounds__(64) void k_wipv_hash1(const uint8_t* __restrict__ proofs, size_t proof_len, int k, int m, int nm, size_t nproofs,
+                                                   const affine_mem* __restrict__ pts, const affine_mem* __restrict__ gens, fq* __restrict__ chal,
+                                                   int* __restrict__ bad) {
+    __shared__ __align__(4) uint8_t lds[64 * MSG_STRIDE];
+    const int jobs = k + 2;
+    size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (gid >= nproofs * jobs) return;
+    size_t pr = gid / jobs;
+    if (bad[pr]) return;
+    wipv_hash1_job(pr, (int)(gid % jobs), lds + threadIdx.x * MSG_STRIDE, proofs, proof_len, k, m, nm, pts, gens, chal, &bad[pr]);
 }
 
 // affine yG; y = 0 makes it the identity (the reference panics at :458 mod_inv unwrap) -> malformed
@@ -735,6 +737,7 @@ __global__ __launch_bounds__(64) void k_wipv_hash2(int k, int m, size_t nproofs,
     chal[pr * CH_COUNT(k) + CH_Z] = msg_result_scalar(buf, pos);
 }
 
+template <bool SPLIT = true>
 __device__ __forceinline__ void wipv_consts_body(size_t pr, const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k,
                                                  size_t nproofs, const fq* __restrict__ chal, int c, int W, tdig_t* __restrict__ digF,
                                                  fqm* __restrict__ scF, fq* __restrict__ varS, fqm* __restrict__ cst, int* __restrict__ bad) {
@@ -832,7 +835,7 @@ __device__ __forceinline__ void wipv_consts_body(size_t pr, const uint8_t* __res
     cs[CS_Z] = fqm_mul(esq, z_m);               // e^2 z                      :539
     cs[CS_A] = fqm_mul(e_m, r_m);               // e r'                       :538
     cs[CS_B] = fqm_mul(e_m, s_m);               // e s'                       :548
-    bpv_split_tables(cs, k, m);
+    if (SPLIT) bpv_split_tables(cs, k, m);
 }
 
 __global__ __launch_bounds__(64) void k_wipv_consts(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
@@ -874,11 +877,104 @@ __global__ __launch_bounds__(64) void k_bpv_consts_pre(unsigned cblocks, const u
     ec_slice_table(P, slice, pretab + (pr * (size_t)lpp + idx) * ECMUL_NT, nparts);
 }
 
+// Bulletproofs+ form of k_bpv_chain: the scalar side of one proof in one 64-lane workgroup (hash1 on k + 2 lanes -> y*G on eight
+// -> affine -> z -> constants -> split tables -> G_i / H_i digits), the window tables of k_bpv_small's ladders in the workgroups
+// nproofs.. of the same launch.  Six launches before (launch_wipv_scalar_pipeline below).
+__global__ __launch_bounds__(64) void k_wipv_chain(const uint8_t* __restrict__ proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs,
+                                                   const affine_mem* __restrict__ pts, const affine_mem* __restrict__ gens,
+                                                   const affine_mem* __restrict__ table, int c, int W, tdig_t* __restrict__ digF, fq* __restrict__ varS,
+                                                   fq* chal, fqm* cst, affine_mem* fixaff, int* bad, int ibase, int nm_tab, xyzz* __restrict__ pretab,
+                                                   int lpp, int nparts) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x >= nproofs) {  // window tables of the (point, slice) lanes of k_bpv_small: scalar-independent
+        const size_t g = (size_t)(blockIdx.x - nproofs) * 64 + tid;
+        const size_t pr = g / (size_t)lpp;
+        const int idx = (int)(g % (size_t)lpp);
+        const int NPT = 3 + 2 * k + m, NV = 2 + 2 * k + m;
+        const int nsl = 2 * nparts;
+        if (pr >= nproofs || idx >= nsl * NV) return;
+        const int v = idx / nsl, slice = idx % nsl;
+        const affine P = affine_load(pts[pr * NPT + 1 + v]);
+        if (affine_is_inf(P)) return;
+        ec_slice_table(P, slice, pretab + (pr * (size_t)lpp + idx) * ECMUL_NT, nparts);
+        return;
+    }
+    __shared__ __align__(4) uint8_t lds[(BPV_MAXK + 2) * MSG_STRIDE];
+    __shared__ xyzz red[8];
+    __shared__ int s_bad;
+    const size_t pr = blockIdx.x;
+    if (tid == 0) s_bad = bad[pr];
+    __syncthreads();
+    if (s_bad) return;
+    // y, e, x_j
+    if (tid < k + 2) wipv_hash1_job(pr, tid, lds + tid * MSG_STRIDE, proofs, proof_len, k, m, nm_tab, pts, gens, chal, &s_bad);
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) atomicOr(&bad[pr], 1);
+        return;
+    }
+    // y * generator on eight lanes (windows dealt round-robin), three tree levels                  range_proof_wip.rs:423
+    if (tid < 8) {
+        const int NB = 1 << (c - 1);
+        const fq sc = chal[pr * CH_COUNT(k) + CH_Y];
+        xyzz acc = xyzz_inf();
+        uint32_t carry = 0;
+        for (int w = 0; w < W; w++) {
+            const int d = window_digit(sc, c, w, carry);
+            if ((w & 7) == tid && d != 0) {
+                affine e = affine_load(table[((size_t)ibase * W + w) * NB + ((d < 0 ? -d : d) - 1)]);
+                xyzz_madd_s(acc, e, d < 0);
+            }
+        }
+        red[tid] = acc;
+    }
+    __syncthreads();
+    for (int off = 4; off >= 1; off >>= 1) {
+        if (tid < off) {
+            xyzz v = red[tid];
+            xyzz o = red[tid + off];
+            xyzz_add(v, o);
+            red[tid] = v;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const xyzz a = red[0];
+        if (xyzz_is_inf(a)) {  // y = 0 (the reference panics at :458)
+            s_bad = 1;
+        } else {
+            fixaff[pr * 2] = affine_store(xyzz_to_affine_var(a));
+            // z = H(A, yG)                                                       :424
+            int pos = 0;
+            msg_put_point(lds, pos, pts[pr * (3 + 2 * k + m) + 1]);
+            msg_put_point(lds, pos, fixaff[pr * 2]);
+            chal[pr * CH_COUNT(k) + CH_Z] = msg_result_scalar(lds, pos);
+            wipv_consts_body<false>(pr, proofs, proof_len, n_bits, m, k, nproofs, chal, c, W, digF, nullptr, varS, cst, bad);
+        }
+    }
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) atomicOr(&bad[pr], 1);
+        return;
+    }
+    for (int e = tid; e < 2 * ((1 << CS_LOBITS(k)) + (1 << CS_HIBITS(k))); e += 64) bpv_split_entry(cst + pr * CS_COUNT(k, m), k, m, e);
+    __syncthreads();
+    const int nm = n_bits * m;
+    for (int i = tid; i < nm; i += 64) bpv_vec_elem(pr, i, n_bits, m, k, cst, c, W, digF, nullptr, 1);
+}
+
 hipError_t launch_wipv_scalar_pipeline(const uint8_t* proofs, size_t proof_len, int n_bits, int m, int k, size_t nproofs, const affine_mem* pts,
                                        const affine_mem* gens, const affine_mem* table, int c, int W, tdig_t* digF, fqm* scF, fq* varS, fq* chal,
                                        fq* cst, xyzz* fixres, affine_mem* fixaff, int* bad, hipStream_t st, int ibase, int nm_tab, xyzz* pretab,
                                        int lpp, int nparts) {
     const int nm = n_bits * m;
+    static const bool unchained = bp_tune("BP_VERIFY_SMALL_UNCHAINED") != nullptr;  // A/B: the six-launch form
+    if (pretab && lpp > 0 && !scF && k <= BPV_MAXK && !unchained && nproofs * (size_t)lpp <= 32768) {  // as launch_bpv_scalar_pipeline
+        const unsigned blocks = (unsigned)(nproofs + (nproofs * (size_t)lpp + 63) / 64);
+        hipLaunchKernelGGL(k_wipv_chain, dim3(blocks), dim3(64), 0, st, proofs, proof_len, n_bits, m, k, nproofs, pts, gens, table, c, W, digF, varS,
+                           chal, reinterpret_cast<fqm*>(cst), fixaff, bad, ibase, nm_tab, pretab, lpp, nparts);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_wipv_hash1, dim3((unsigned)((nproofs * (k + 2) + 63) / 64)), dim3(64), 0, st, proofs, proof_len, k, m, nm_tab, nproofs, pts,
                        gens, chal, bad);
     hipLaunchKernelGGL(k_bpv_fixmul, dim3((unsigned)((nproofs + 256 / (2 * FM_SUB) - 1) / (256 / (2 * FM_SUB)))), dim3(256), 0, st, k, nm_tab, nproofs,
