@@ -15,6 +15,7 @@
 
 #include "ec.h"
 #include "ecmul.h"
+#include "ecwave.h"
 #include "fq.h"
 #include "kernels.h"
 
@@ -23,18 +24,8 @@ namespace bp {
 #define FB_T 256
 
 __device__ __forceinline__ xyzz fb_block_sum(xyzz acc, xyzz* red, int tid) {
-    red[tid] = acc;
-    __syncthreads();
-    for (int off = FB_T / 2; off >= 1; off >>= 1) {
-        if (tid < off) {
-            xyzz v = red[tid];
-            xyzz o = red[tid + off];
-            xyzz_add(v, o);
-            red[tid] = v;
-        }
-        __syncthreads();
-    }
-    return red[0];
+    xyzz_group_tree<FB_T>(acc, tid, tid, red);  // two levels across the waves through LDS, six inside wave 0 (ecwave.h)
+    return acc;                                  // valid in thread 0
 }
 
 __global__ __launch_bounds__(FB_T) void k_fb_acc(const affine_mem* __restrict__ table, int W, int NB, const tdig_t* __restrict__ dig,

@@ -94,7 +94,7 @@ hipError_t launch_xyzz_to_affine(const xyzz* in, affine_mem* out, size_t n, hipS
     return hipGetLastError();
 }
 hipError_t launch_gens_multiples(const affine_mem* basesA, size_t nidx, int NB, xyzz* tmp, hipStream_t st) {
-    int segs = NB / 8192;  // chains of at most 8192 additions
+    int segs = NB / 2048;  // chains of at most 2048 additions (the rows come in groups, verify_api.cpp: enough chains per group to fill the SIMDs)
     if (segs < 1) segs = 1;
     const size_t lanes = nidx * (size_t)segs;
     hipLaunchKernelGGL(k_gens_multiples, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, basesA, nidx, NB, segs, tmp);

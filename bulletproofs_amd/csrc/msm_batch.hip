@@ -12,6 +12,7 @@
 
 #include "ec.h"
 #include "ecmul.h"
+#include "ecwave.h"
 #include "fq.h"
 #include "kernels.h"
 
@@ -60,7 +61,6 @@ __global__ __launch_bounds__(256, 2) void k_mb_msm(size_t njobs, int np, const a
                                                    const affine_mem* __restrict__ xpts, const uint8_t* __restrict__ xsc_be,
                                                    const uint32_t* __restrict__ xoff, xyzz* __restrict__ vartab, affine_mem* __restrict__ varaff, int8_t* __restrict__ vardig,
                                                    xyzz* __restrict__ out) {
-    __shared__ xyzz red[256];
     const int tid = threadIdx.x, lane = tid % MB_TP;
     const size_t job = (size_t)blockIdx.x * (256 / MB_TP) + tid / MB_TP;
     const int NB = 1 << (c - 1);
@@ -87,18 +87,8 @@ __global__ __launch_bounds__(256, 2) void k_mb_msm(size_t njobs, int np, const a
             xyzz_add(acc, t);
         }
     }
-    red[tid] = acc;
-    __syncthreads();
-    for (int off = MB_TP / 2; off >= 1; off >>= 1) {
-        if (lane < off) {
-            xyzz v = red[tid];
-            xyzz o = red[tid + off];
-            xyzz_add(v, o);
-            red[tid] = v;
-        }
-        __syncthreads();
-    }
-    if (lane == 0 && job < njobs) out[job] = red[tid];
+    xyzz_wave_tree<MB_TP>(acc, lane);  // DPP row shifts (ecwave.h)
+    if (lane == 0 && job < njobs) out[job] = acc;
 }
 
 hipError_t launch_mb_digits(const uint8_t* scalars_be, size_t total, int c, int W, tdig_t* digits, hipStream_t st, int mont) {

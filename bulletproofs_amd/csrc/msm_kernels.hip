@@ -17,6 +17,7 @@
 #include "ec.h"
 #include "ecmul.h"
 #include "ecq.h"
+#include "ecwave.h"
 #include "fq.h"
 #include "kernels.h"
 
@@ -273,48 +274,26 @@ template __global__ void k_msm_slice<256>(const affine_mem*, const affine_mem*, 
 // ---------------------------------------------------------------------------------------------
 // wsum[w] = sum over slices of partial[w][s]; one 64-lane workgroup per window.
 __global__ __launch_bounds__(64) void k_msm_reduce_slices(const xyzz* __restrict__ partial, int S, xyzz* __restrict__ wsum) {
-    __shared__ xyzz red[64];
     const int w = blockIdx.x, tid = threadIdx.x;
     xyzz acc = xyzz_inf();
     for (int s = tid; s < S; s += 64) {
         xyzz o = partial[(size_t)w * S + s];
         xyzz_add(acc, o);
     }
-    red[tid] = acc;
-    __syncthreads();
-    for (int off = 32; off >= 1; off >>= 1) {
-        if (tid < off) {
-            xyzz v = red[tid];
-            xyzz o = red[tid + off];
-            xyzz_add(v, o);
-            red[tid] = v;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) wsum[w] = red[0];
+    xyzz_wave_tree<64>(acc, tid);  // DPP / ds_bpermute moves (ecwave.h)
+    if (tid == 0) wsum[w] = acc;
 }
 
 // wsum[w] = sum over parts g of parts[g][w] (multi-GPU combine: one part per rank); one 64-lane workgroup per window.
 __global__ __launch_bounds__(64) void k_msm_reduce_parts(const xyzz* __restrict__ parts, int G, int W, xyzz* __restrict__ wsum) {
-    __shared__ xyzz red[64];
     const int w = blockIdx.x, tid = threadIdx.x;
     xyzz acc = xyzz_inf();
     for (int g = tid; g < G; g += 64) {
         xyzz o = parts[(size_t)g * W + w];
         if (!fp_raw_is_zero(o.ZZ)) xyzz_add(acc, o);
     }
-    red[tid] = acc;
-    __syncthreads();
-    for (int off = 32; off >= 1; off >>= 1) {
-        if (tid < off) {
-            xyzz v = red[tid];
-            xyzz o = red[tid + off];
-            xyzz_add(v, o);
-            red[tid] = v;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) wsum[w] = red[0];
+    xyzz_wave_tree<64>(acc, tid);  // DPP / ds_bpermute moves (ecwave.h)
+    if (tid == 0) wsum[w] = acc;
 }
 
 // Tiny MSMs (n <= 64: the reference's two- to ten-term folds such as T1 = t1 G + tau1 H, range_proof.rs:168, or the
@@ -329,19 +308,9 @@ __global__ __launch_bounds__(256) void k_msm_tiny(const affine_mem* __restrict__
     const int tid = threadIdx.x, v = tid >> 2, slice = tid & 3;
     xyzz acc = xyzz_inf();
     if (v < n) acc = ec_mul_glv_slice(affine_load(pts[v]), fq_from_be_reduce(scalars_be + 32 * (size_t)v), slice, tabs + (size_t)tid * ECMUL_NT);
-    red[tid] = acc;
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-        if (tid < off) {
-            xyzz a = red[tid];
-            xyzz o = red[tid + off];
-            xyzz_add(a, o);
-            red[tid] = a;
-        }
-        __syncthreads();
-    }
+    xyzz_group_tree<256>(acc, tid, tid, red);  // two levels across the waves through LDS, six inside wave 0 (ecwave.h)
     if (tid != 0) return;
-    xyzz r = red[0];
+    xyzz r = acc;
     if (init) xyzz_madd(r, affine_load(*init));
     affine_mem m = affine_store(xyzz_to_affine_var(r));
     if (out_limbs) *out_limbs = m;

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ec.h"
+#include "ecwave.h"
 #include "fq.h"
 #include "kernels.h"
 
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(PV_T) void k_pv_fold(int nm, int n, const uint8_t* 
 template <int TP>
 __global__ __launch_bounds__(256, 3) void k_pv_msm(size_t njobs, const affine_mem* __restrict__ table, int c, const pv_ent* __restrict__ ent,
                                                    size_t stride, int cnt0, int cnt1, int parts, xyzz* __restrict__ out) {
-    __shared__ xyzz red[256];
+    __shared__ xyzz red[TP > 64 ? 256 : 1];
     const int tid = threadIdx.x, lane = tid % TP;
     const size_t unit = (size_t)blockIdx.x * (256 / TP) + tid / TP;  // (job, part)
     const size_t job = unit / (size_t)parts;
@@ -307,20 +308,7 @@ __global__ __launch_bounds__(256, 3) void k_pv_msm(size_t njobs, const affine_me
             tB = tN;
         }
     }
-    if (TP > 1) {
-        red[tid] = acc;
-        __syncthreads();
-        for (int off = TP / 2; off >= 1; off >>= 1) {
-            if (lane < off) {
-                xyzz v = red[tid];
-                xyzz o = red[tid + off];
-                xyzz_add(v, o);
-                red[tid] = v;
-            }
-            __syncthreads();
-        }
-        acc = red[tid];
-    }
+    xyzz_group_tree<TP>(acc, lane, tid, red);  // in the wave: DPP / ds_bpermute moves, no LDS (ecwave.h)
     if (lane == 0 && job < njobs) out[unit] = acc;
 }
 __global__ void k_pv_msm_combine(size_t njobs, int parts, const xyzz* __restrict__ partial, xyzz* __restrict__ out) {

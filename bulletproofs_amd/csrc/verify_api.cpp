@@ -1,4 +1,5 @@
 // C ABI: generator tables (bp_gens) and the batched range-proof verifier.  Host plumbing only.
+#include <algorithm>
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
@@ -22,10 +23,14 @@ using namespace bp;
     } while (0)
 
 #define BP_MAX_TABLE_WINDOW 20
+// XYZZ scratch of the table build: rows are built in groups of at most this many bytes (round 2 built all rows at once: 2.25x
+// the table, 119 GiB beside the 52.8 GiB table of n=64 m=1; a group of 8 GiB still gives every SIMD a chain)
+#define BP_GENS_TMP_BYTES ((size_t)8 << 30)
 #define BP_NOALLOC_SCRATCH_BYTES (64u << 20)  // 64 MiB per GPU, see bp_rangeproof_verify_batch_device_noalloc
 static int pick_table_window(int np) {
     // widest c in [4, 20] whose table (np * W * 2^(c-1) * 64 B) stays <= 64 GiB of the 288 GB HBM and whose build
-    // (table + 2.25x as XYZZ scratch, freed afterwards) fits in 80 % of the memory that is free right now.
+    // (table + the XYZZ scratch of one group of rows, at most BP_GENS_TMP_BYTES, freed afterwards) fits in 80 % of the
+    // memory that is free right now.
     // n=64 m=1: c = 20, 52.8 GiB, 13 gathers per generator term (c = 16: 4.3 GiB, 17 gathers); measured with a
     // 68 GiB table (scripts/experiments/bigtable_test.py, profiles/r02_bigtable_gather.txt): a table addition costs
     // 10 % more than from a 5.5 GiB table (74.9 -> 82.1 ps) while the wider window removes 4 of 17 additions per
@@ -35,7 +40,7 @@ static int pick_table_window(int np) {
     int best = 4;
     for (int c = 4; c <= BP_MAX_TABLE_WINDOW; c++) {
         size_t bytes = (size_t)np * (256 / c + 1) * ((size_t)1 << (c - 1)) * 64;
-        double need = (double)bytes * 3.25 + (double)((size_t)2 << 30);
+        double need = (double)bytes + (double)std::min<size_t>(bytes / 64 * 144, BP_GENS_TMP_BYTES) + (double)((size_t)2 << 30);
         if (bytes <= ((size_t)64 << 30) && need <= 0.8 * (double)free_b) best = c;
     }
     return best;
@@ -122,14 +127,20 @@ static int gens_create_locked(bp_ctx* ctx, const uint8_t* g_xy, const uint8_t* h
     GCHK(hipMalloc((void**)&g->d_table, g->table_bytes));
     GCHK(hipMalloc((void**)&d_bases, nidx * sizeof(xyzz)));
     GCHK(hipMalloc((void**)&d_basesA, nidx * sizeof(affine_mem)));
-    GCHK(hipMalloc((void**)&d_tmp, nent * sizeof(xyzz)));
+    size_t rows_per = BP_GENS_TMP_BYTES / ((size_t)NB * sizeof(xyzz));
+    if (rows_per < 1) rows_per = 1;
+    if (rows_per > nidx) rows_per = nidx;
+    GCHK(hipMalloc((void**)&d_tmp, rows_per * NB * sizeof(xyzz)));
     GCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), st));
     GCHK(hipMemcpyAsync(d_be, host.data(), (size_t)np * 64, hipMemcpyHostToDevice, st));
     GCHK(launch_ingest_points(d_be, g->d_pts, np, ctx->d_err, st));
     GCHK(launch_gens_bases(g->d_pts, np, c, W, d_bases, st));
     GCHK(launch_xyzz_to_affine(d_bases, d_basesA, nidx, st));
-    GCHK(launch_gens_multiples(d_basesA, nidx, NB, d_tmp, st));
-    GCHK(launch_gens_normalize(d_tmp, nent, g->d_table, st));
+    for (size_t r0 = 0; r0 < nidx; r0 += rows_per) {  // stream-ordered: a group's scratch is normalized before the next group overwrites it
+        const size_t nr = std::min(rows_per, nidx - r0);
+        GCHK(launch_gens_multiples(d_basesA + r0, nr, NB, d_tmp, st));
+        GCHK(launch_gens_normalize(d_tmp, nr * NB, g->d_table + r0 * NB, st));
+    }
     int h_err = 0;
     GCHK(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
     GCHK(hipStreamSynchronize(st));

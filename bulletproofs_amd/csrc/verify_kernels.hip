@@ -22,6 +22,7 @@
 
 #include "ec.h"
 #include "ecmul.h"
+#include "ecwave.h"
 #include "fq.h"
 #include "kernels.h"
 
@@ -149,14 +150,16 @@ template <int TP>
 __global__ __launch_bounds__(256, BPV_FIX_WAVES) void k_bpv_fix(int nm, size_t nproofs, const affine_mem* __restrict__ table, int c, int W,
                                                     const tdig_t* __restrict__ digF, const int* __restrict__ bad, int shiftW,
                                                     xyzz* __restrict__ fixpart) {
-    __shared__ xyzz red[256];
+    // Trees of one or two levels (the large batches) on DPP moves (ecwave.h); the longer ones stay in LDS (ds_bpermute levels
+    // measured no gain here: the tree is 5 of this kernel's ~75 additions per lane and three waves per SIMD hide the barriers)
+    __shared__ xyzz red[TP > 4 ? 256 : 1];
     const int tid = threadIdx.x;
     const int lane = tid % TP;
     const size_t pr = (size_t)blockIdx.x * (256 / TP) + tid / TP;
     const bool active = pr < nproofs && !bad[pr];
     xyzz acc = xyzz_inf();
     if (active) acc = bpv_fix_lane_sum<TP>(lane, nm, table, c, W, digF + pr * (size_t)((2 * nm + 2) * W), shiftW);
-    if (TP > 1) {
+    if constexpr (TP > 4) {
         red[tid] = acc;
         __syncthreads();
         for (int off = TP / 2; off >= 1; off >>= 1) {
@@ -169,6 +172,8 @@ __global__ __launch_bounds__(256, BPV_FIX_WAVES) void k_bpv_fix(int nm, size_t n
             __syncthreads();
         }
         acc = red[tid];
+    } else {
+        xyzz_wave_tree<TP>(acc, lane);
     }
     if (lane == 0 && pr < nproofs) fixpart[pr] = acc;
 }
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
                                                  int wip, xyzz* __restrict__ varpart) {
     // varpart != nullptr: k_bpv_fix runs BESIDE this kernel on the helper stream (launch_bpv_msm), so the sum does not start from
     // fixpart[pr]; the proof-specific sum alone goes to varpart[pr] and k_bpv_verdict finishes
-    __shared__ xyzz red[256];
+    __shared__ xyzz red[TP > 64 ? 256 : 1];
     const int tid = threadIdx.x;
     const int lane = tid % TP;
     const size_t pr = (size_t)blockIdx.x * (256 / TP) + tid / TP;
@@ -219,26 +224,16 @@ __global__ __launch_bounds__(256, BPV_MSM_WAVES) void k_bpv_msm(int n_bits, int 
             xyzz_add(acc, t);
         }
     }
-    red[tid] = acc;
-    __syncthreads();
-    for (int off = TP / 2; off >= 1; off >>= 1) {
-        if (lane < off) {
-            xyzz v = red[tid];
-            xyzz o = red[tid + off];
-            xyzz_add(v, o);
-            red[tid] = v;
-        }
-        __syncthreads();
-    }
+    xyzz_group_tree<TP>(acc, lane, tid, red);
     if (lane == 0 && pr < nproofs && varpart) {
-        varpart[pr] = red[tid];
+        varpart[pr] = acc;
     } else if (lane == 0 && pr < nproofs) {
         uint8_t verdict;
         if (bad[pr]) {
             verdict = 255;
         } else {
             // lhs == A ?  (range_proof.rs:777; == b_tag, range_proof_wip.rs:604) compared projectively: X = A.x*ZZ, Y = A.y*ZZZ
-            xyzz r = red[tid];
+            xyzz r = acc;
             affine A = affine_load(pts[pr * NPT]);
             bool eq = !xyzz_is_inf(r) && fp_eq(r.X, fp_mul(A.x, r.ZZ)) && fp_eq(r.Y, fp_mul(A.y, r.ZZZ));
             verdict = eq ? 0 : 3;
@@ -257,7 +252,7 @@ __global__ __launch_bounds__(256) void k_bpv_msm_slice(int m, int k, size_t npro
                                                         const xyzz* __restrict__ fixpart, const fq* __restrict__ varS, xyzz* __restrict__ vartab,
                                                         const int* __restrict__ bad, uint8_t* __restrict__ verdicts, int wip,
                                                         xyzz* __restrict__ varpart) {  // varpart: as in k_bpv_msm
-    __shared__ xyzz red[256];
+    __shared__ xyzz red[LPP > 64 ? 256 : 1];
     const int tid = threadIdx.x;
     const int lane = tid % LPP;
     const size_t pr = (size_t)blockIdx.x * (256 / LPP) + tid / LPP;
@@ -278,25 +273,15 @@ __global__ __launch_bounds__(256) void k_bpv_msm_slice(int m, int k, size_t npro
             xyzz_add(acc, t);
         }
     }
-    red[tid] = acc;
-    __syncthreads();
-    for (int off = LPP / 2; off >= 1; off >>= 1) {
-        if (lane < off) {
-            xyzz v = red[tid];
-            xyzz o = red[tid + off];
-            xyzz_add(v, o);
-            red[tid] = v;
-        }
-        __syncthreads();
-    }
+    xyzz_group_tree<LPP>(acc, lane, tid, red);
     if (lane == 0 && pr < nproofs && varpart) {
-        varpart[pr] = red[tid];
+        varpart[pr] = acc;
     } else if (lane == 0 && pr < nproofs) {
         uint8_t verdict;
         if (bad[pr]) {
             verdict = 255;
         } else {
-            xyzz r = red[tid];
+            xyzz r = acc;
             affine A = affine_load(pts[pr * NPT]);
             bool eq = !xyzz_is_inf(r) && fp_eq(r.X, fp_mul(A.x, r.ZZ)) && fp_eq(r.Y, fp_mul(A.y, r.ZZZ));
             verdict = eq ? 0 : 3;
@@ -336,7 +321,7 @@ __global__ __launch_bounds__(256) void k_bpv_small(int nm, int m, int k, size_t 
                                                     const fq* __restrict__ varS, xyzz* __restrict__ vartab, const int* __restrict__ bad,
                                                     uint8_t* __restrict__ verdicts, int wip, int pre) {
     static_assert(2 * LPP <= 256, "one proof fits a workgroup");
-    __shared__ xyzz red[256];
+    __shared__ xyzz red[2 * LPP > 64 ? 256 : 1];
     const int tid = threadIdx.x;
     const int sub = tid % (2 * LPP), lane = sub % LPP;
     const bool fixrole = sub >= LPP;
@@ -364,23 +349,13 @@ __global__ __launch_bounds__(256) void k_bpv_small(int nm, int m, int k, size_t 
             }
         }
     }
-    red[tid] = acc;
-    __syncthreads();
-    for (int off = LPP; off >= 1; off >>= 1) {
-        if (sub < off) {
-            xyzz v = red[tid];
-            xyzz o = red[tid + off];
-            xyzz_add(v, o);
-            red[tid] = v;
-        }
-        __syncthreads();
-    }
+    xyzz_group_tree<2 * LPP>(acc, sub, tid, red);
     if (sub == 0 && pr < nproofs) {
         uint8_t verdict;
         if (bad[pr]) {
             verdict = 255;
         } else {
-            xyzz r = red[tid];
+            xyzz r = acc;
             affine A = affine_load(pts[pr * NPT]);
             bool eq = !xyzz_is_inf(r) && fp_eq(r.X, fp_mul(A.x, r.ZZ)) && fp_eq(r.Y, fp_mul(A.y, r.ZZZ));
             verdict = eq ? 0 : 3;

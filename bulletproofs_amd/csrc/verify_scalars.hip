@@ -17,6 +17,7 @@
 #include "ecmul.h"
 #include "fq.h"
 #include "kernels.h"
+#include "ecwave.h"
 #include "sha256.h"
 
 namespace bp {
@@ -219,7 +220,6 @@ __device__ __forceinline__ void store_digits(const fq& kk, int c, int W, tdig_t*
 __global__ __launch_bounds__(256) void k_bpv_fixmul(int k, int nm, size_t nproofs, const affine_mem* __restrict__ table, int c, int W,
                                                     const fq* __restrict__ chal, xyzz* __restrict__ fixres, const int* __restrict__ bad, int nmul,
                                                     int ibase) {
-    __shared__ xyzz red[256];
     const int tid = threadIdx.x, lane = tid % (2 * FM_SUB), sub = lane % FM_SUB, which = lane / FM_SUB;
     const size_t pr = (size_t)blockIdx.x * (256 / (2 * FM_SUB)) + tid / (2 * FM_SUB);
     const int NB = 1 << (c - 1);
@@ -238,18 +238,8 @@ __global__ __launch_bounds__(256) void k_bpv_fixmul(int k, int nm, size_t nproof
             }
         }
     }
-    red[tid] = acc;
-    __syncthreads();
-    for (int off = FM_SUB / 2; off >= 1; off >>= 1) {
-        if (sub < off) {
-            xyzz v = red[tid];
-            xyzz o = red[tid + off];
-            xyzz_add(v, o);
-            red[tid] = v;
-        }
-        __syncthreads();
-    }
-    if (sub == 0 && pr < nproofs) fixres[pr * 2 + which] = red[tid];
+    xyzz_wave_tree<FM_SUB>(acc, sub);
+    if (sub == 0 && pr < nproofs) fixres[pr * 2 + which] = acc;
 }
 
 // affine yG, ux with ONE inversion (Montgomery's trick on the two ZZZ).  y = 0 or x_u = 0 makes a
@@ -570,7 +560,7 @@ __global__ __launch_bounds__(64) void k_bpv_chain(const uint8_t* __restrict__ pr
         return;
     }
     __shared__ __align__(4) uint8_t lds[(BPV_MAXK + 1) * MSG_STRIDE];
-    __shared__ xyzz red[16];
+    __shared__ xyzz red[2];
     __shared__ int s_bad;
     const size_t pr = blockIdx.x;
     if (tid == 0) s_bad = bad[pr];
@@ -598,19 +588,11 @@ __global__ __launch_bounds__(64) void k_bpv_chain(const uint8_t* __restrict__ pr
                 xyzz_madd_s(acc, e, d < 0);
             }
         }
-        red[tid] = acc;
+        xyzz_wave_tree<8>(acc, sub);  // lanes 0..15 = one DPP row
+        if (sub == 0) red[which] = acc;
     }
     __syncthreads();
-    for (int off = 4; off >= 1; off >>= 1) {
-        if (tid < 16 && (tid & 7) < off) {
-            xyzz v = red[tid];
-            xyzz o = red[tid + off];
-            xyzz_add(v, o);
-            red[tid] = v;
-        }
-        __syncthreads();
-    }
-    if (tid == 0 && !bpv_fixinv_body(red[0], red[8], fixaff + pr * 2)) s_bad = 1;
+    if (tid == 0 && !bpv_fixinv_body(red[0], red[1], fixaff + pr * 2)) s_bad = 1;
     __syncthreads();
     if (s_bad) {
         if (tid == 0) atomicOr(&bad[pr], 1);
@@ -900,7 +882,7 @@ __global__ __launch_bounds__(64) void k_wipv_chain(const uint8_t* __restrict__ p
         return;
     }
     __shared__ __align__(4) uint8_t lds[(BPV_MAXK + 2) * MSG_STRIDE];
-    __shared__ xyzz red[8];
+    __shared__ xyzz red[1];
     __shared__ int s_bad;
     const size_t pr = blockIdx.x;
     if (tid == 0) s_bad = bad[pr];
@@ -926,18 +908,10 @@ __global__ __launch_bounds__(64) void k_wipv_chain(const uint8_t* __restrict__ p
                 xyzz_madd_s(acc, e, d < 0);
             }
         }
-        red[tid] = acc;
+        xyzz_wave_tree<8>(acc, tid);
+        if (tid == 0) red[0] = acc;
     }
     __syncthreads();
-    for (int off = 4; off >= 1; off >>= 1) {
-        if (tid < off) {
-            xyzz v = red[tid];
-            xyzz o = red[tid + off];
-            xyzz_add(v, o);
-            red[tid] = v;
-        }
-        __syncthreads();
-    }
     if (tid == 0) {
         const xyzz a = red[0];
         if (xyzz_is_inf(a)) {  // y = 0 (the reference panics at :458)
