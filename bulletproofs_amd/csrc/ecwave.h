@@ -10,6 +10,7 @@
 // (the moves read the partner's registers); the sum is valid in the lane with sub == 0.
 #pragma once
 #include "ec.h"
+#include "ecq.h"
 
 #if defined(__HIPCC__)
 namespace bp {
@@ -97,6 +98,37 @@ __device__ __forceinline__ void xyzz_group_tree(xyzz& acc, int sub, int tid, xyz
         }
     } else {
         xyzz_wave_tree<G>(acc, sub);
+    }
+}
+
+// Latency-bound trees (one workgroup alone on its CU: the single-proof MSMs, the small-batch verifier): from the level at which
+// a group has four lanes per addition left, the additions are shared by QUADS (ecq.h: 2.2 times less latency than a lane's own
+// addition).  Group of G lanes (G = 64 .. 256, a divisor of the 256-thread workgroup, groups aligned to G), lane `sub` of its
+// group, `gbase` = the group's first slot in `red` (256 entries).  Level 1: the lower half adds the upper half, one addition
+// per lane; then G/4 quads halve the G/2 partials level by level, operands replicated over a quad by LDS broadcast reads.
+// Every thread of the workgroup must call; the sum is valid in the lanes of the group's first quad (sub < 4).
+template <int G>
+__device__ __forceinline__ void xyzz_group_tree_quad(xyzz& acc, int sub, int gbase, xyzz* red) {
+    static_assert(G >= 8 && G <= 256 && (G & (G - 1)) == 0, "group of 8..256 lanes");
+    red[gbase + sub] = acc;
+    __syncthreads();
+    if (sub < G / 2) {
+        xyzz v = red[gbase + sub];
+        xyzz o = red[gbase + sub + G / 2];
+        xyzz_add(v, o);
+        red[gbase + sub] = v;
+    }
+    __syncthreads();
+    const int q = sub & 3, j = sub >> 2;
+#pragma nounroll
+    for (int cnt = G / 4; cnt >= 1; cnt >>= 1) {
+        if (j < cnt) {
+            acc = red[gbase + j];
+            xyzz o = red[gbase + j + cnt];
+            xyzzq_add(q, acc, o);
+            if (q == 0 && cnt > 1) red[gbase + j] = acc;
+        }
+        __syncthreads();
     }
 }
 

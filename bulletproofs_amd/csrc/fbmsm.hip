@@ -24,8 +24,8 @@ namespace bp {
 #define FB_T 256
 
 __device__ __forceinline__ xyzz fb_block_sum(xyzz acc, xyzz* red, int tid) {
-    xyzz_group_tree<FB_T>(acc, tid, tid, red);  // two levels across the waves through LDS, six inside wave 0 (ecwave.h)
-    return acc;                                  // valid in thread 0
+    xyzz_group_tree_quad<FB_T>(acc, tid, 0, red);  // one level of single-lane additions, seven of quad-shared ones (ecwave.h)
+    return acc;                                     // valid in thread 0
 }
 
 __global__ __launch_bounds__(FB_T) void k_fb_acc(const affine_mem* __restrict__ table, int W, int NB, const tdig_t* __restrict__ dig,

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_msm_tiny(const affine_mem* __restrict__
     const int tid = threadIdx.x, v = tid >> 2, slice = tid & 3;
     xyzz acc = xyzz_inf();
     if (v < n) acc = ec_mul_glv_slice(affine_load(pts[v]), fq_from_be_reduce(scalars_be + 32 * (size_t)v), slice, tabs + (size_t)tid * ECMUL_NT);
-    xyzz_group_tree<256>(acc, tid, tid, red);  // two levels across the waves through LDS, six inside wave 0 (ecwave.h)
+    xyzz_group_tree_quad<256>(acc, tid, 0, red);  // one level of single-lane additions, seven of quad-shared ones (ecwave.h)
     if (tid != 0) return;
     xyzz r = acc;
     if (init) xyzz_madd(r, affine_load(*init));

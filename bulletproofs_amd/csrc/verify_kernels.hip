@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k_bpv_small(int nm, int m, int k, size_t 
                                                     const fq* __restrict__ varS, xyzz* __restrict__ vartab, const int* __restrict__ bad,
                                                     uint8_t* __restrict__ verdicts, int wip, int pre) {
     static_assert(2 * LPP <= 256, "one proof fits a workgroup");
-    __shared__ xyzz red[2 * LPP > 64 ? 256 : 1];
+    __shared__ xyzz red[256];
     const int tid = threadIdx.x;
     const int sub = tid % (2 * LPP), lane = sub % LPP;
     const bool fixrole = sub >= LPP;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_bpv_small(int nm, int m, int k, size_t 
             }
         }
     }
-    xyzz_group_tree<2 * LPP>(acc, sub, tid, red);
+    xyzz_group_tree_quad<2 * LPP>(acc, sub, tid - sub, red);  // latency-bound: quad-shared additions from the second level on
     if (sub == 0 && pr < nproofs) {
         uint8_t verdict;
         if (bad[pr]) {
