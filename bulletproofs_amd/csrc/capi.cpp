@@ -443,6 +443,8 @@ void bp_ctx_destroy(bp_ctx* ctx) {
     if (ctx->v_ev_side) (void)hipEventDestroy(ctx->v_ev_side);
     if (ctx->v_ev_fork) (void)hipEventDestroy(ctx->v_ev_fork);
     if (ctx->v_ev_join) (void)hipEventDestroy(ctx->v_ev_join);
+    if (ctx->ev_fbpre) (void)hipEventDestroy(ctx->ev_fbpre);
+    if (ctx->ev_fbpre0) (void)hipEventDestroy(ctx->ev_fbpre0);
     if (!ctx->stream_borrowed) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

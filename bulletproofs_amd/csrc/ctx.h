@@ -92,6 +92,11 @@ struct bp_ctx {
     bp::DevBuf proto[6];  // protocol layer (proto.cpp): folded bases, hi_tag, staging
     bp::DevBuf rlc[3];    // random-linear-combination batch verifier (rlc_kernels.hip): weights, MSM scalars, misc
     bp::DevBuf fb[3];     // fixed-table MSM of the protocol layer (fbmsm.hip): inputs, digits, partials + output
+    // single-proof verifiers: window tables of the proof's points built on the side stream ahead of the MSM (proto.cpp FbPretab)
+    bp::DevBuf fbpre;
+    void* h_fbpre = nullptr;                               // pinned staging of the points (64 KiB, allocated at first use)
+    hipEvent_t ev_fbpre = nullptr, ev_fbpre0 = nullptr;    // tables built (side stream) / ctx->stream's earlier work done
+    int fbpre_n = 0;  // points whose tables are pending in ctx->vartab (0 = none)
     void* h_pin = nullptr;  // pinned host staging for the protocol layer's small uploads / read-backs (grow-only)
     size_t h_pin_cap = 0;
     void release_all() {
@@ -112,6 +117,9 @@ struct bp_ctx {
         fixpart.release();
         for (auto& s : proto) s.release();
         for (auto& s : fb) s.release();
+        fbpre.release();
+        if (h_fbpre) (void)hipHostFree(h_fbpre);
+        h_fbpre = nullptr;
         for (auto& s : rlc) s.release();
         if (h_pin) (void)hipHostFree(h_pin);
         h_pin = nullptr;

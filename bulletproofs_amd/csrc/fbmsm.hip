@@ -32,7 +32,7 @@ __global__ __launch_bounds__(FB_T) void k_fb_acc(const affine_mem* __restrict__ 
                                                  const uint32_t* __restrict__ gidx, const uint32_t* __restrict__ toff,
                                                  const affine_mem* __restrict__ xpts, const uint8_t* __restrict__ xsc_be,
                                                  const uint32_t* __restrict__ xoff, int nblk, int nxblk, xyzz* __restrict__ vartab,
-                                                 xyzz* __restrict__ partial) {
+                                                 xyzz* __restrict__ partial, int pre) {
     __shared__ xyzz red[FB_T];
     const int tid = threadIdx.x, blk = blockIdx.x, job = blockIdx.y;
     xyzz acc = xyzz_inf();
@@ -56,7 +56,10 @@ __global__ __launch_bounds__(FB_T) void k_fb_acc(const affine_mem* __restrict__ 
         // longest lane is what counts
         const int slice = tid & 3;
         for (uint32_t v = x0 + (uint32_t)(xb * FB_T + tid) / 4; v < x1; v += (uint32_t)nxblk * (FB_T / 4)) {
-            xyzz r = ec_mul_glv_slice(affine_load(xpts[v]), fq_from_be_reduce(xsc_be + 32 * (size_t)v), slice, tab);
+            // pre: the slice's window table is already there (k_fb_pretab, built while the caller derived the scalars)
+            const affine Pv = affine_load(xpts[v]);
+            const fq kv = fq_from_be_reduce(xsc_be + 32 * (size_t)v);
+            xyzz r = !pre ? ec_mul_glv_slice(Pv, kv, slice, tab) : affine_is_inf(Pv) ? xyzz_inf() : ec_slice_ladder(kv, slice, tab);
             xyzz_add(acc, r);
         }
     }
@@ -76,15 +79,38 @@ __global__ __launch_bounds__(FB_T) void k_fb_final(const xyzz* __restrict__ part
     if (tid == 0) affine_to_be64(out_be + 64 * (size_t)job, xyzz_to_affine_var(s));
 }
 
+// The scalar-independent half of a single job's job-specific points, ahead of the call: lane 4 p + slice builds the window table
+// k_fb_acc's lane (block (4 p + slice) / FB_T, thread (4 p + slice) % FB_T) of job 0 would build for point p - 68 of the top
+// slices' 128 doublings.  The single-proof verifiers know their proof's points before they know the scalars (two transcript
+// hashes, a fixed-base round trip and the whole scalar vector lie in between): the tables are built on the side stream meanwhile.
+__global__ __launch_bounds__(FB_T) void k_fb_pretab(const uint8_t* __restrict__ xbe, int nx, xyzz* __restrict__ vartab) {
+    const int L = blockIdx.x * FB_T + threadIdx.x, p = L >> 2, slice = L & 3;
+    if (p >= nx) return;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(xbe + 64 * (size_t)p);
+    affine_mem m;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        m.x.w[k] = __builtin_bswap32(src[7 - k]);
+        m.y.w[k] = __builtin_bswap32(src[15 - k]);
+    }
+    if (!affine_mem_valid(m, false)) return;  // infinity / not on the curve: the call itself skips or rejects the point
+    ec_slice_table(affine_load(m), slice, vartab + (size_t)L * ECMUL_NT);
+}
+hipError_t launch_fb_pretab(const uint8_t* xbe, int nx, xyzz* vartab, hipStream_t st) {
+    if (nx <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fb_pretab, dim3((unsigned)((4 * nx + FB_T - 1) / FB_T)), dim3(FB_T), 0, st, xbe, nx, vartab);
+    return hipGetLastError();
+}
+
 size_t fb_vartab_bytes(size_t njobs, int nxblk) { return njobs * (size_t)nxblk * FB_T * ECMUL_NT * sizeof(xyzz); }
 
 // nblk: blocks per job over the generator items (>= 1); nxblk: blocks per job over the extras (0 = none)
 hipError_t launch_fb_msm(size_t njobs, const affine_mem* table, int W, int NB, const tdig_t* dig, const uint32_t* gidx, const uint32_t* toff,
                          const affine_mem* xpts, const uint8_t* xsc_be, const uint32_t* xoff, int nblk, int nxblk, xyzz* vartab, xyzz* partial,
-                         uint8_t* out_be, hipStream_t st) {
+                         uint8_t* out_be, hipStream_t st, int pre) {
     if (njobs == 0) return hipSuccess;
     hipLaunchKernelGGL(k_fb_acc, dim3((unsigned)(nblk + nxblk), (unsigned)njobs), dim3(FB_T), 0, st, table, W, NB, dig, gidx, toff, xpts, xsc_be,
-                       xoff, nblk, nxblk, vartab, partial);
+                       xoff, nblk, nxblk, vartab, partial, pre);
     hipLaunchKernelGGL(k_fb_final, dim3((unsigned)njobs), dim3(FB_T), 0, st, partial, nblk + nxblk, out_be);
     return hipGetLastError();
 }

@@ -177,7 +177,49 @@ int pin_reserve(bp_ctx* ctx, size_t bytes) {
     return BP_OK;
 }
 
-int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_in, Pt* out, const std::vector<const FbJob*>* jobs_ptr = nullptr) {
+// Single-proof verifiers: the window tables of the proof's points (the scalar-independent half of their ladders: the top slices'
+// 68 base doublings and the 8-entry tables, ~0.2 ms of one workgroup) start on the context's side stream as soon as the proof is
+// parsed and run beside the transcript hashes, the y*G round trip and the host's scalar vector; the ONE-job MSM that follows
+// (use_pre) waits for them and runs the ladders only (k_fb_acc 469 -> ~265 us).  The guard orders ctx->stream after the table
+// kernel on every exit path, so that nothing later on that stream touches ctx->vartab while it is still being written.
+struct FbPretab {
+    bp_ctx* ctx;
+    explicit FbPretab(bp_ctx* c) : ctx(c) {}
+    int begin(const std::vector<Pt>& pts, bool batched) {
+        const int nx = (int)pts.size();
+        if (batched || nx == 0 || nx > 1024) return BP_OK;  // (a batch prover's rendezvous merges jobs: its layout is not this one)
+        hipStream_t side;
+        HIPCHK(ctx->side_stream(&side), "hipStreamCreate");
+        if (!ctx->ev_fbpre) {
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_fbpre, hipEventDisableTiming), "hipEventCreate");
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_fbpre0, hipEventDisableTiming), "hipEventCreate");
+            HIPCHK(hipHostMalloc(&ctx->h_fbpre, (size_t)1024 * 64, hipHostMallocDefault), "hipHostMalloc");
+        } else {
+            HIPCHK(hipEventSynchronize(ctx->ev_fbpre), "event sync");  // the previous call's upload has left the staging buffer
+        }
+        const int nxblk = (4 * nx + 255) / 256;
+        RC(ctx->vartab.reserve(fb_vartab_bytes(1, nxblk)));
+        RC(ctx->fbpre.reserve((size_t)nx * 64));
+        memcpy(ctx->h_fbpre, pts.data(), (size_t)nx * 64);
+        // ctx->vartab is free once everything queued on ctx->stream has run
+        HIPCHK(hipEventRecord(ctx->ev_fbpre0, ctx->stream), "record event");
+        HIPCHK(hipStreamWaitEvent(side, ctx->ev_fbpre0, 0), "wait event");
+        HIPCHK(hipMemcpyAsync(ctx->fbpre.p, ctx->h_fbpre, (size_t)nx * 64, hipMemcpyHostToDevice, side), "h2d");
+        HIPCHK(launch_fb_pretab((const uint8_t*)ctx->fbpre.p, nx, (xyzz*)ctx->vartab.p, side), "fb_pretab");
+        HIPCHK(hipEventRecord(ctx->ev_fbpre, side), "record event");
+        ctx->fbpre_n = nx;
+        return BP_OK;
+    }
+    ~FbPretab() {
+        if (ctx->fbpre_n) {
+            (void)hipStreamWaitEvent(ctx->stream, ctx->ev_fbpre, 0);
+            ctx->fbpre_n = 0;
+        }
+    }
+};
+
+int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_in, Pt* out, const std::vector<const FbJob*>* jobs_ptr = nullptr,
+                 bool use_pre = false) {
     // jobs either by value (one caller) or as pointers into several callers' vectors (FbBatcher)
     struct View {
         const std::vector<FbJob>* v;
@@ -240,6 +282,12 @@ int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_i
     h_toff[nj] = (uint32_t)t;
     h_xoff[nj] = (uint32_t)x;
     hipStream_t st = ctx->stream;
+    int pre = 0;
+    if (use_pre && ctx->fbpre_n && nj == 1 && nx == (size_t)ctx->fbpre_n) {  // the tables of exactly these points, in this order
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_fbpre, 0), "wait event");
+        ctx->fbpre_n = 0;
+        pre = 1;
+    }
     uint8_t* d = (uint8_t*)ctx->fb[0].p;
     affine_mem* d_xpts = (affine_mem*)(d + o_xpts);
     xyzz* d_partial = (xyzz*)ctx->fb[2].p;
@@ -250,7 +298,7 @@ int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_i
     if (nx) HIPCHK(launch_ingest_points(d + o_xbe, d_xpts, nx, d_err, st), "ingest");
     if (nt) HIPCHK(launch_mb_digits(d + o_sc, nt, g->c, W, (tdig_t*)ctx->fb[1].p, st, 1), "digits");
     HIPCHK(launch_fb_msm(nj, g->d_table, W, NB, (const tdig_t*)ctx->fb[1].p, (const uint32_t*)(d + o_gidx), (const uint32_t*)(d + o_toff), d_xpts,
-                         d + o_xsc, (const uint32_t*)(d + o_xoff), nblk, nxblk, (xyzz*)ctx->vartab.p, d_partial, d_out, st),
+                         d + o_xsc, (const uint32_t*)(d + o_xoff), nblk, nxblk, (xyzz*)ctx->vartab.p, d_partial, d_out, st, pre),
            "fb_msm");
     uint8_t* h_out = hp + up_bytes;
     HIPCHK(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st), "d2h");
@@ -276,9 +324,9 @@ struct FbBatcher : StepRendezvous<FbJob, Pt> {
 };
 thread_local FbBatcher* tl_batcher = nullptr;
 
-int fbmsm(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs, Pt* out) {
+int fbmsm(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs, Pt* out, bool use_pre = false) {
     if (tl_batcher) return tl_batcher->submit(jobs, out);
-    return fbmsm_direct(ctx, g, jobs, out);
+    return fbmsm_direct(ctx, g, jobs, out, nullptr, use_pre);
 }
 
 // ---- shared pieces -------------------------------------------------------------------------------
@@ -892,6 +940,17 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
     }
     const Fq ONE(1), ZERO;
     const size_t iG = 2 * nm, iH = 2 * nm + 1;
+    FbPretab pretab(ctx);
+    if (mode == 2) {  // the MSM's proof-specific points in the order the job lists them below
+        std::vector<Pt> xp;
+        xp.push_back(pf.S);
+        for (int j = 0; j < k; j++) xp.push_back(pf.ipa.L[j]);
+        for (int j = 0; j < k; j++) xp.push_back(pf.ipa.R[j]);
+        for (int j = 0; j < m; j++) xp.push_back(V[j]);
+        xp.push_back(pf.T1);
+        xp.push_back(pf.T2);
+        RC(pretab.begin(xp, tl_batcher != nullptr));
+    }
     Fq y = Transcript().point(pf.A.b).point(pf.S.b).result_scalar();
     Fq xu = Transcript().bigint32(pf.tau_x_be).bigint32(pf.miu_be).bigint32(pf.tx_be).result_scalar();
     std::vector<FbJob> jobs(2);
@@ -948,7 +1007,7 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
         jb.extra(pf.T1, cver * x);
         jb.extra(pf.T2, cver * x * x);
         Pt lhs;
-        RC(fbmsm(ctx, gens, jobs, &lhs));
+        RC(fbmsm(ctx, gens, jobs, &lhs, true));
         *verdict = (lhs == pf.A) ? BP_VERDICT_OK : BP_VERDICT_RANGE_PROOF_ERROR;  // :777
         return BP_OK;
     }
@@ -1333,6 +1392,16 @@ int bp_wip_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
         }
     }
     const size_t iG = 2 * nm, iH = 2 * nm + 1;
+    FbPretab pretab(ctx);
+    if (mode == 2) {  // the MSM's proof-specific points in the order the job lists them below
+        std::vector<Pt> xp;
+        for (int j = 0; j < k; j++) xp.push_back(pf.w.L[j]);
+        for (int j = 0; j < k; j++) xp.push_back(pf.w.R[j]);
+        xp.push_back(pf.A);
+        for (int j = 0; j < m; j++) xp.push_back(V[j]);
+        xp.push_back(pf.w.a_tag);
+        RC(pretab.begin(xp, tl_batcher != nullptr));
+    }
     Fq y = Transcript().point(pf.A.b).result_scalar();
     Pt yG;
     std::vector<FbJob> jobs(1);
@@ -1368,7 +1437,7 @@ int bp_wip_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
         for (int j = 0; j < m; j++) jb.extra(V[j], ps.z2m[j] * mey);  // :568-571
         jb.extra(pf.w.a_tag, -e);                                     // :574
         Pt lhs;
-        RC(fbmsm(ctx, gens, jobs, &lhs));
+        RC(fbmsm(ctx, gens, jobs, &lhs, true));
         *verdict = (lhs == pf.w.b_tag) ? BP_VERDICT_OK : BP_VERDICT_RANGE_PROOF_ERROR;  // :604
         return BP_OK;
     }
