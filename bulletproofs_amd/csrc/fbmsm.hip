@@ -67,7 +67,10 @@ __global__ __launch_bounds__(FB_T) void k_fb_acc(const affine_mem* __restrict__ 
     if (tid == 0) partial[(size_t)job * (nblk + nxblk) + blk] = s;
 }
 
-__global__ __launch_bounds__(FB_T) void k_fb_final(const xyzz* __restrict__ partial, int nparts, uint8_t* __restrict__ out_be) {
+// out_raw != nullptr: the sum itself (XYZZ, 144 bytes) for callers that finish on the host - with a handful of jobs the one
+// division-step inversion of a lone lane is ~45 us of this kernel's ~55, and the host (same code, ec.h) does it in ~2 us
+__global__ __launch_bounds__(FB_T) void k_fb_final(const xyzz* __restrict__ partial, int nparts, uint8_t* __restrict__ out_be,
+                                                   xyzz* __restrict__ out_raw) {
     __shared__ xyzz red[FB_T];
     const int tid = threadIdx.x, job = blockIdx.x;
     xyzz acc = xyzz_inf();
@@ -76,7 +79,12 @@ __global__ __launch_bounds__(FB_T) void k_fb_final(const xyzz* __restrict__ part
         xyzz_add(acc, o);
     }
     xyzz s = fb_block_sum(acc, red, tid);
-    if (tid == 0) affine_to_be64(out_be + 64 * (size_t)job, xyzz_to_affine_var(s));
+    if (tid == 0) {
+        if (out_raw)
+            out_raw[job] = s;
+        else
+            affine_to_be64(out_be + 64 * (size_t)job, xyzz_to_affine_var(s));
+    }
 }
 
 // The scalar-independent half of a single job's job-specific points, ahead of the call: lane 4 p + slice builds the window table
@@ -107,11 +115,11 @@ size_t fb_vartab_bytes(size_t njobs, int nxblk) { return njobs * (size_t)nxblk *
 // nblk: blocks per job over the generator items (>= 1); nxblk: blocks per job over the extras (0 = none)
 hipError_t launch_fb_msm(size_t njobs, const affine_mem* table, int W, int NB, const tdig_t* dig, const uint32_t* gidx, const uint32_t* toff,
                          const affine_mem* xpts, const uint8_t* xsc_be, const uint32_t* xoff, int nblk, int nxblk, xyzz* vartab, xyzz* partial,
-                         uint8_t* out_be, hipStream_t st, int pre) {
+                         uint8_t* out_be, hipStream_t st, int pre, xyzz* out_raw) {
     if (njobs == 0) return hipSuccess;
     hipLaunchKernelGGL(k_fb_acc, dim3((unsigned)(nblk + nxblk), (unsigned)njobs), dim3(FB_T), 0, st, table, W, NB, dig, gidx, toff, xpts, xsc_be,
                        xoff, nblk, nxblk, vartab, partial, pre);
-    hipLaunchKernelGGL(k_fb_final, dim3((unsigned)njobs), dim3(FB_T), 0, st, partial, nblk + nxblk, out_be);
+    hipLaunchKernelGGL(k_fb_final, dim3((unsigned)njobs), dim3(FB_T), 0, st, partial, nblk + nxblk, out_be, out_raw);
     return hipGetLastError();
 }
 

@@ -252,7 +252,10 @@ int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_i
     const size_t o_sc = 0, o_xsc = o_sc + nta * 32, o_xbe = o_xsc + nxa * 32, o_gidx = o_xbe + nxa * 64, o_toff = o_gidx + nta * 4,
                  o_xoff = o_toff + (nj + 1) * 4, up_bytes = o_xoff + (nj + 1) * 4;
     const size_t o_xpts = (up_bytes + 63) / 64 * 64;
-    const size_t out_bytes = nj * 64 + sizeof(int);
+    // a handful of jobs (the single-proof calls): the sums come back as XYZZ and the host does the inversions (k_fb_final)
+    const bool raw = nj <= 8;
+    const size_t o_raw = (nj * 64 + sizeof(int) + 15) / 16 * 16;
+    const size_t out_bytes = raw ? o_raw + nj * sizeof(xyzz) : nj * 64 + sizeof(int);
     RC(pin_reserve(ctx, up_bytes + out_bytes));
     RC(ctx->fb[0].reserve(o_xpts + nxa * sizeof(affine_mem)));
     RC(ctx->fb[1].reserve(nta * (size_t)W * sizeof(tdig_t)));
@@ -298,7 +301,8 @@ int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_i
     if (nx) HIPCHK(launch_ingest_points(d + o_xbe, d_xpts, nx, d_err, st), "ingest");
     if (nt) HIPCHK(launch_mb_digits(d + o_sc, nt, g->c, W, (tdig_t*)ctx->fb[1].p, st, 1), "digits");
     HIPCHK(launch_fb_msm(nj, g->d_table, W, NB, (const tdig_t*)ctx->fb[1].p, (const uint32_t*)(d + o_gidx), (const uint32_t*)(d + o_toff), d_xpts,
-                         d + o_xsc, (const uint32_t*)(d + o_xoff), nblk, nxblk, (xyzz*)ctx->vartab.p, d_partial, d_out, st, pre),
+                         d + o_xsc, (const uint32_t*)(d + o_xoff), nblk, nxblk, (xyzz*)ctx->vartab.p, d_partial, d_out, st, pre,
+                         raw ? (xyzz*)(d_out + o_raw) : nullptr),
            "fb_msm");
     uint8_t* h_out = hp + up_bytes;
     HIPCHK(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st), "d2h");
@@ -309,7 +313,15 @@ int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_i
         set_error_msg("input point not on curve");
         return BP_EPOINT;
     }
-    for (size_t j = 0; j < nj; j++) memcpy(out[j].b, h_out + 64 * j, 64);
+    for (size_t j = 0; j < nj; j++) {
+        if (raw) {
+            xyzz sum;
+            memcpy(&sum, h_out + o_raw + j * sizeof(xyzz), sizeof(xyzz));
+            affine_to_be64(out[j].b, xyzz_to_affine_var(sum));  // the code k_fb_final runs otherwise: the same bytes
+        } else {
+            memcpy(out[j].b, h_out + 64 * j, 64);
+        }
+    }
     return BP_OK;
 }
 
