@@ -296,7 +296,7 @@ int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_i
     xyzz* d_partial = (xyzz*)ctx->fb[2].p;
     uint8_t* d_out = (uint8_t*)(d_partial + nj * (size_t)nparts);
     int* d_err = (int*)(d_out + nj * 64);
-    HIPCHK(hipMemsetAsync(d_err, 0, sizeof(int), st), "memset");
+    if (nx) HIPCHK(hipMemsetAsync(d_err, 0, sizeof(int), st), "memset");  // (only k_ingest_points raises the flag)
     HIPCHK(hipMemcpyAsync(d, hp, up_bytes, hipMemcpyHostToDevice, st), "h2d");
     if (nx) HIPCHK(launch_ingest_points(d + o_xbe, d_xpts, nx, d_err, st), "ingest");
     if (nt) HIPCHK(launch_mb_digits(d + o_sc, nt, g->c, W, (tdig_t*)ctx->fb[1].p, st, 1), "digits");
@@ -307,8 +307,8 @@ int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_i
     uint8_t* h_out = hp + up_bytes;
     HIPCHK(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st), "d2h");
     HIPCHK(hipStreamSynchronize(st), "sync");
-    int h_err;
-    memcpy(&h_err, h_out + nj * 64, sizeof(int));
+    int h_err = 0;
+    if (nx) memcpy(&h_err, h_out + nj * 64, sizeof(int));
     if (h_err) {
         set_error_msg("input point not on curve");
         return BP_EPOINT;
