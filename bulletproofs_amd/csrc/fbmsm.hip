@@ -53,13 +53,16 @@ __global__ __launch_bounds__(FB_T) void k_fb_acc(const affine_mem* __restrict__ 
         const int xb = blk - nblk;
         xyzz* tab = vartab + (((size_t)job * nxblk + xb) * FB_T + tid) * ECMUL_NT;
         // four lanes per job-specific point (ec_mul_glv_slice): these calls wait for the result, so the length of the
-        // longest lane is what counts
-        const int slice = tid & 3;
-        for (uint32_t v = x0 + (uint32_t)(xb * FB_T + tid) / 4; v < x1; v += (uint32_t)nxblk * (FB_T / 4)) {
+        // longest lane is what counts.  pre = window ranges per GLV half of tables that are already there (k_fb_pretab: 4, i.e.
+        // 2 pre lanes per point - with three ranges a ladder is 44 doublings and 11 additions).
+        const int spp = pre ? 2 * pre : 4;
+        const uint32_t lane = (uint32_t)(xb * FB_T + tid);  // (pre: one pass, lane = spp * point + slice as in k_fb_pretab)
+        const int slice = (int)(lane % spp);
+        for (uint32_t v = x0 + lane / spp; v < x1; v += pre ? 0xffffffffu - v : (uint32_t)nxblk * (FB_T / spp)) {
             // pre: the slice's window table is already there (k_fb_pretab, built while the caller derived the scalars)
             const affine Pv = affine_load(xpts[v]);
             const fq kv = fq_from_be_reduce(xsc_be + 32 * (size_t)v);
-            xyzz r = !pre ? ec_mul_glv_slice(Pv, kv, slice, tab) : affine_is_inf(Pv) ? xyzz_inf() : ec_slice_ladder(kv, slice, tab);
+            xyzz r = !pre ? ec_mul_glv_slice(Pv, kv, slice, tab) : affine_is_inf(Pv) ? xyzz_inf() : ec_slice_ladder(kv, slice, tab, pre);
             xyzz_add(acc, r);
         }
     }
@@ -87,12 +90,14 @@ __global__ __launch_bounds__(FB_T) void k_fb_final(const xyzz* __restrict__ part
     }
 }
 
-// The scalar-independent half of a single job's job-specific points, ahead of the call: lane 4 p + slice builds the window table
-// k_fb_acc's lane (block (4 p + slice) / FB_T, thread (4 p + slice) % FB_T) of job 0 would build for point p - 68 of the top
-// slices' 128 doublings.  The single-proof verifiers know their proof's points before they know the scalars (two transcript
+// The scalar-independent half of a single job's job-specific points, ahead of the call: lane 6 p + slice builds the window table
+// that k_fb_acc's lane (block (6 p + slice) / FB_T, thread (6 p + slice) % FB_T) of job 0 reads for point p.  FB_PRE_PARTS = 3
+// window ranges per GLV half, six lanes per point: built ahead of time the tables cost the call nothing as long as they are ready
+// when the scalars are - measured on C1: two ranges 199 us of tables (hidden) + 298 us of ladders, four ranges 361 us (73 us of them
+// exposed) + 179 us, three ranges 88 doublings in the tables and 44 doublings + 11 additions in a ladder.  The single-proof verifiers know their proof's points before they know the scalars (two transcript
 // hashes, a fixed-base round trip and the whole scalar vector lie in between): the tables are built on the side stream meanwhile.
 __global__ __launch_bounds__(FB_T) void k_fb_pretab(const uint8_t* __restrict__ xbe, int nx, xyzz* __restrict__ vartab) {
-    const int L = blockIdx.x * FB_T + threadIdx.x, p = L >> 2, slice = L & 3;
+    const int L = blockIdx.x * FB_T + threadIdx.x, p = L / (2 * FB_PRE_PARTS), slice = L % (2 * FB_PRE_PARTS);
     if (p >= nx) return;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(xbe + 64 * (size_t)p);
     affine_mem m;
@@ -102,11 +107,11 @@ __global__ __launch_bounds__(FB_T) void k_fb_pretab(const uint8_t* __restrict__ 
         m.y.w[k] = __builtin_bswap32(src[15 - k]);
     }
     if (!affine_mem_valid(m, false)) return;  // infinity / not on the curve: the call itself skips or rejects the point
-    ec_slice_table(affine_load(m), slice, vartab + (size_t)L * ECMUL_NT);
+    ec_slice_table(affine_load(m), slice, vartab + (size_t)L * ECMUL_NT, FB_PRE_PARTS);
 }
 hipError_t launch_fb_pretab(const uint8_t* xbe, int nx, xyzz* vartab, hipStream_t st) {
     if (nx <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_fb_pretab, dim3((unsigned)((4 * nx + FB_T - 1) / FB_T)), dim3(FB_T), 0, st, xbe, nx, vartab);
+    hipLaunchKernelGGL(k_fb_pretab, dim3((unsigned)((2 * FB_PRE_PARTS * nx + FB_T - 1) / FB_T)), dim3(FB_T), 0, st, xbe, nx, vartab);
     return hipGetLastError();
 }
 

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -180,7 +181,7 @@ int pin_reserve(bp_ctx* ctx, size_t bytes) {
 // Single-proof verifiers: the window tables of the proof's points (the scalar-independent half of their ladders: the top slices'
 // 68 base doublings and the 8-entry tables, ~0.2 ms of one workgroup) start on the context's side stream as soon as the proof is
 // parsed and run beside the transcript hashes, the y*G round trip and the host's scalar vector; the ONE-job MSM that follows
-// (use_pre) waits for them and runs the ladders only (k_fb_acc 469 -> ~265 us).  The guard orders ctx->stream after the table
+// (use_pre) waits for them and runs the ladders only.  The guard orders ctx->stream after the table
 // kernel on every exit path, so that nothing later on that stream touches ctx->vartab while it is still being written.
 struct FbPretab {
     bp_ctx* ctx;
@@ -197,7 +198,7 @@ struct FbPretab {
         } else {
             HIPCHK(hipEventSynchronize(ctx->ev_fbpre), "event sync");  // the previous call's upload has left the staging buffer
         }
-        const int nxblk = (4 * nx + 255) / 256;
+        const int nxblk = (2 * FB_PRE_PARTS * nx + 255) / 256;
         RC(ctx->vartab.reserve(fb_vartab_bytes(1, nxblk)));
         RC(ctx->fbpre.reserve((size_t)nx * 64));
         memcpy(ctx->h_fbpre, pts.data(), (size_t)nx * 64);
@@ -218,8 +219,9 @@ struct FbPretab {
     }
 };
 
+// `meanwhile` (optional): host work of the caller that does not need the results, run between the last launch and the wait
 int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_in, Pt* out, const std::vector<const FbJob*>* jobs_ptr = nullptr,
-                 bool use_pre = false) {
+                 bool use_pre = false, const std::function<void()>* meanwhile = nullptr) {
     // jobs either by value (one caller) or as pointers into several callers' vectors (FbBatcher)
     struct View {
         const std::vector<FbJob>* v;
@@ -242,7 +244,9 @@ int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_i
     int nblk = (int)((max_t * (size_t)W + 255) / 256);
     if (nblk < 1) nblk = 1;
     if (nblk > 128) nblk = 128;
-    const int nxblk = (int)((4 * max_x + 255) / 256);  // four lanes per job-specific point (ec_mul_glv_slice)
+    // the window tables of exactly these points, in this order, are being built (FbPretab): 2 FB_PRE_PARTS lanes per point
+    const bool pre_ok = use_pre && ctx->fbpre_n && nj == 1 && nx == (size_t)ctx->fbpre_n;
+    const int nxblk = (int)(((pre_ok ? 2 * FB_PRE_PARTS : 4) * max_x + 255) / 256);  // else four lanes per job-specific point (ec_mul_glv_slice)
     if (nxblk > 64 || nt >= ((size_t)1 << 31) || nx >= ((size_t)1 << 31)) {
         set_error_msg("internal: fixed-table MSM job too large");
         return BP_EINVAL;
@@ -286,10 +290,10 @@ int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_i
     h_xoff[nj] = (uint32_t)x;
     hipStream_t st = ctx->stream;
     int pre = 0;
-    if (use_pre && ctx->fbpre_n && nj == 1 && nx == (size_t)ctx->fbpre_n) {  // the tables of exactly these points, in this order
+    if (pre_ok) {
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_fbpre, 0), "wait event");
         ctx->fbpre_n = 0;
-        pre = 1;
+        pre = FB_PRE_PARTS;
     }
     uint8_t* d = (uint8_t*)ctx->fb[0].p;
     affine_mem* d_xpts = (affine_mem*)(d + o_xpts);
@@ -306,6 +310,7 @@ int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_i
            "fb_msm");
     uint8_t* h_out = hp + up_bytes;
     HIPCHK(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st), "d2h");
+    if (meanwhile) (*meanwhile)();
     HIPCHK(hipStreamSynchronize(st), "sync");
     int h_err = 0;
     if (nx) memcpy(&h_err, h_out + nj * 64, sizeof(int));
@@ -336,9 +341,13 @@ struct FbBatcher : StepRendezvous<FbJob, Pt> {
 };
 thread_local FbBatcher* tl_batcher = nullptr;
 
-int fbmsm(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs, Pt* out, bool use_pre = false) {
-    if (tl_batcher) return tl_batcher->submit(jobs, out);
-    return fbmsm_direct(ctx, g, jobs, out, nullptr, use_pre);
+int fbmsm(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs, Pt* out, bool use_pre = false,
+          const std::function<void()>* meanwhile = nullptr) {
+    if (tl_batcher) {
+        if (meanwhile) (*meanwhile)();
+        return tl_batcher->submit(jobs, out);
+    }
+    return fbmsm_direct(ctx, g, jobs, out, nullptr, use_pre, meanwhile);
 }
 
 // ---- shared pieces -------------------------------------------------------------------------------
@@ -537,13 +546,33 @@ int ipa_prove_fixed(bp_ctx* ctx, const bp_gens* g, std::vector<Fq> cH, const Fq&
 }
 
 // challenges x_j of an IPA proof and the s vector (inner_product.rs:276-306)
+// out[i] = in[i]^-1 for non-zero inputs with ONE exponentiation (Montgomery's trick): the host inversion is Fermat's chain,
+// ~12 us, and a verifier has log2(nm) + 1 of them on its critical path between two GPU calls
+void batch_inv(const std::vector<Fq>& in, std::vector<Fq>& out) {
+    const size_t n = in.size();
+    out.resize(n);
+    if (!n) return;
+    std::vector<Fq> pref(n);
+    Fq run = in[0];
+    pref[0] = run;
+    for (size_t i = 1; i < n; i++) {
+        run = run * in[i];
+        pref[i] = run;
+    }
+    Fq inv = run.inv();
+    for (size_t i = n - 1; i >= 1; i--) {
+        out[i] = inv * pref[i - 1];
+        inv = inv * in[i];
+    }
+    out[0] = inv;
+}
 int ipa_challenges(const Ipa& p, const Pt& ux, std::vector<Fq>& x, std::vector<Fq>& xinv) {
     for (size_t j = 0; j < p.L.size(); j++) {
         Fq c = Transcript().point(p.L[j].b).point(p.R[j].b).point(ux.b).result_scalar();
         if (c.is_zero()) return BP_EINVAL;
         x.push_back(c);
-        xinv.push_back(c.inv());
     }
+    batch_inv(x, xinv);
     return BP_OK;
 }
 std::vector<Fq> s_vector(const std::vector<Fq>& x, const std::vector<Fq>& xinv, size_t n) {
@@ -969,31 +998,36 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
     jobs[0].gen(gens->ibase, y);  // Point::generator() * y, not the caller's G   // base_point * y   (:588)
     jobs[1].gen(iG, xu);  // ux = G * x_u     (:657-658)
     Pt yGux[2];
-    RC(fbmsm(ctx, gens, jobs, yGux));
+    // what needs neither y*G nor ux is computed while the GPU works on them
+    Fq x, cver, sum_y, sum_2n;
+    std::vector<Fq> yi(nm), yinv(nm), vec_2n(n), zpow(m + 2);
+    const std::function<void()> host_part = [&]() {
+        x = Transcript().point(pf.T1.b).point(pf.T2.b).point(gn.Gh.b).point(gn.Hh.b).result_scalar();
+        if (mode == 2)
+            cver = Transcript().point(pf.A.b).point(pf.S.b).point(pf.T1.b).point(pf.T2.b).point(gn.Gh.b).point(gn.Hh.b).result_scalar();
+        if (y.is_zero()) return;
+        Fq yi1 = y.inv();
+        yi[0] = yinv[0] = ONE;
+        for (size_t i = 1; i < nm; i++) {
+            yi[i] = yi[i - 1] * y;
+            yinv[i] = yinv[i - 1] * yi1;
+        }
+        vec_2n[0] = ONE;
+        for (size_t i = 1; i < n; i++) vec_2n[i] = vec_2n[i - 1] + vec_2n[i - 1];
+        for (size_t i = 0; i < nm; i++) sum_y = sum_y + yi[i];
+        for (size_t i = 0; i < n; i++) sum_2n = sum_2n + vec_2n[i];
+    };
+    RC(fbmsm(ctx, gens, jobs, yGux, false, &host_part));
     const Pt &yG = yGux[0], &ux = yGux[1];
     if (y.is_zero() || yG.is_inf() || ux.is_inf()) {
         *verdict = BP_VERDICT_MALFORMED;
         return BP_OK;
     }
     Fq z = Transcript().point(yG.b).result_scalar();
-    Fq x = Transcript().point(pf.T1.b).point(pf.T2.b).point(gn.Gh.b).point(gn.Hh.b).result_scalar();
-    std::vector<Fq> yi(nm), yinv(nm), vec_2n(n), zpow(m + 2);
-    Fq yi1 = y.inv();
-    yi[0] = yinv[0] = ONE;
-    for (size_t i = 1; i < nm; i++) {
-        yi[i] = yi[i - 1] * y;
-        yinv[i] = yinv[i - 1] * yi1;
-    }
-    vec_2n[0] = ONE;
-    for (size_t i = 1; i < n; i++) vec_2n[i] = vec_2n[i - 1] + vec_2n[i - 1];
     for (int j = 0; j < m + 2; j++) zpow[j] = z.pow(2 + (uint64_t)j);
-    Fq sum_y, sum_2n;
-    for (size_t i = 0; i < nm; i++) sum_y = sum_y + yi[i];
-    for (size_t i = 0; i < n; i++) sum_2n = sum_2n + vec_2n[i];
 
     if (mode == 2) {
         // aggregated_verify (:537-782): one MSM - generator terms from the table, proof points by GLV ladders
-        Fq cver = Transcript().point(pf.A.b).point(pf.S.b).point(pf.T1.b).point(pf.T2.b).point(gn.Gh.b).point(gn.Hh.b).result_scalar();
         std::vector<Fq> xs, xinv;
         if (ipa_challenges(pf.ipa, ux, xs, xinv) != BP_OK) {
             *verdict = BP_VERDICT_MALFORMED;
@@ -1278,11 +1312,14 @@ bool wip_challenges(const WipArg& w, const Pt& gh, const Pt& hh, size_t n, const
         Fq x = Transcript().point(w.L[j].b).point(w.R[j].b).point(gh.b).point(hh.b).result_scalar();
         if (x.is_zero()) return false;
         c.x.push_back(x);
-        c.xinv.push_back(x.inv());
     }
     if (y.is_zero()) return false;
+    std::vector<Fq> all_in(c.x), all_out;  // the x_j and y with one exponentiation
+    all_in.push_back(y);
+    batch_inv(all_in, all_out);
+    c.xinv.assign(all_out.begin(), all_out.end() - 1);
     c.s = s_vector(c.x, c.xinv, n);
-    Fq yinv = y.inv(), yp = yinv;
+    Fq yinv = all_out.back(), yp = yinv;
     c.sg.resize(n);
     c.sh.resize(n);
     Fq all(1);
