@@ -484,12 +484,14 @@ int ipa_prove(bp_ctx* ctx, const affine_mem* G0, const affine_mem* H0, size_t n,
     return BP_OK;
 }
 
-// fn(lo, hi) over [0, n) on up to four host threads (blocks of >= 512 indices): the per-round loops of the single-proof
-// provers are 4 nm independent scalar products - ~110 us at nm = 1024, ~0.5 ms at nm = 4096 - between two GPU calls that take
-// 65 us.  Not under a batch prover's rendezvous, whose callers are already one thread per proof.
+// fn(lo, hi) over [0, n) on up to four host threads: the per-round loops of the single-proof provers are 4 nm independent
+// scalar products - ~110 us at nm = 1024, ~250 us at nm = 4096 - between two GPU calls that take 65-85 us.  Not under a batch
+// prover's rendezvous, whose callers are already one thread per proof.
 template <class F>
 void host_blocks(size_t n, bool allow_threads, F fn) {
-    const size_t nthr = !allow_threads ? 1 : n >= 2048 ? 4 : n >= 1024 ? 2 : 1;
+    // measured (bench.py --workload prove): four threads from nm = 4096 (C4 prove 6.2 -> 5.6 ms); two threads at nm = 1024 cost
+    // more in thread start-up than they save (C2 2.33 -> 2.52 ms)
+    const size_t nthr = !allow_threads ? 1 : n >= 4096 ? 4 : 1;
     if (nthr == 1) {
         fn((size_t)0, n);
         return;
