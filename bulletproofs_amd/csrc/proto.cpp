@@ -1566,6 +1566,102 @@ int bp_wip_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
         return BP_OK;
     }
     Fq z = Transcript().point(pf.A.b).point(yG.b).result_scalar();
+    if (mode == 2) {
+        // aggregated_verify (:388-609).  The 2 nm generator scalars
+        //   G_i : (e r') s_i y^-i + e^2 z                                          :540-545
+        //   H_i : (e s') s_i^-1 - e^2 z - e^2 d_i y^(nm-i),  d_i = 2^(i mod n) z^(2(1 + i/n))   :549-557
+        // are derived block by block on the host workers (host_blocks): every block starts its four running products directly
+        // (s_lo and s_(nm-1-lo) from the index bits, the two powers of y by exponentiation) and steps them by one product each -
+        // s_(i+1) = s_i * ratio[trailing ones of i], s_(j-1) = s_j * iratio[trailing zeros of j] - 8 products per i instead of the
+        // 13 of the vector-by-vector form (plus_common + wip_challenges, kept for `verify`), and zeta from the closed forms
+        // sum y^(i+1) = y (y^nm - 1)/(y - 1), sum d_i = (2^n - 1) sum_j z^(2(j+1)).  n=64 m=64: 0.94 ms of host work -> see DESIGN.md.
+        const Fq e = Transcript().point(pf.w.a_tag.b).point(pf.w.b_tag.b).point(gn.Gh.b).point(gn.Hh.b).result_scalar();
+        std::vector<Fq> xs;
+        for (int j = 0; j < k; j++) {
+            Fq xj = Transcript().point(pf.w.L[j].b).point(pf.w.R[j].b).point(gn.Gh.b).point(gn.Hh.b).result_scalar();
+            if (xj.is_zero()) {
+                *verdict = BP_VERDICT_MALFORMED;
+                return BP_OK;
+            }
+            xs.push_back(xj);
+        }
+        const Fq ONE(1);
+        const Fq ym1 = y - ONE;
+        const bool y_is_one = ym1.is_zero();
+        std::vector<Fq> inv_in(xs), inv_out;  // x_j, y, y - 1 with one exponentiation
+        inv_in.push_back(y);
+        if (!y_is_one) inv_in.push_back(ym1);
+        batch_inv(inv_in, inv_out);
+        const Fq yinv = inv_out[k];
+        const Fq esq = e * e, er = pf.w.r_prime * e, es = pf.w.s_prime * e, esz = z * esq, zsq = z * z;
+        // bit b of i selects x_(k-1-b) (set) or its inverse (clear) in s_i  (weighted_inner_product.rs:430-455 as s_vector above)
+        std::vector<Fq> xsq(k), xisq(k), ratio(k), iratio(k);
+        for (int b = 0; b < k; b++) {
+            xsq[b] = xs[k - 1 - b] * xs[k - 1 - b];
+            xisq[b] = inv_out[k - 1 - b] * inv_out[k - 1 - b];
+        }
+        {
+            Fq down = ONE, up = ONE;  // prod_{b<t} x_b^-2, prod_{b<t} x_b^2
+            for (int t = 0; t < k; t++) {
+                ratio[t] = xsq[t] * down;
+                iratio[t] = xisq[t] * up;
+                down = down * xisq[t];
+                up = up * xsq[t];
+            }
+        }
+        auto s_at = [&](size_t i) {
+            Fq p = ONE;
+            for (int b = 0; b < k; b++) p = p * (((i >> b) & 1) ? xs[k - 1 - b] : inv_out[k - 1 - b]);
+            return p;
+        };
+        std::vector<Fq> v2(n), z2m(m);
+        v2[0] = ONE;
+        for (size_t i = 1; i < n; i++) v2[i] = v2[i - 1] + v2[i - 1];
+        z2m[0] = zsq;
+        for (int j = 1; j < m; j++) z2m[j] = z2m[j - 1] * zsq;
+        jobs.assign(1, FbJob());
+        FbJob& jb = jobs[0];
+        job_slots(jb, 2 * nm);
+        host_blocks(nm, tl_batcher == nullptr, [&](size_t lo, size_t hi) {
+            Fq si = s_at(lo), sj = s_at(nm - 1 - lo);               // s_i, s_(nm-1-i)
+            Fq gy = er * yinv.pow(lo), hy = esq * y.pow(nm - lo);    // (e r') y^-i, e^2 y^(nm-i)
+            for (size_t i = lo; i < hi; i++) {
+                jb.gi[2 * i] = (uint32_t)i, jb.gs[2 * i] = gy * si + esz;
+                const Fq d = v2[i % n] * z2m[i / n];
+                jb.gi[2 * i + 1] = (uint32_t)(nm + i), jb.gs[2 * i + 1] = (es * sj - esz) - d * hy;
+                if (i + 1 < hi) {
+                    si = si * ratio[__builtin_ctzll(~(unsigned long long)i)];
+                    sj = sj * iratio[__builtin_ctzll((unsigned long long)(nm - 1 - i))];
+                    gy = gy * yinv;
+                    hy = hy * yinv;
+                }
+            }
+        });
+        // zeta = (z - z^2) sum_i y^(i+1) - z y^(nm+1) sum_i d_i                       :521-531
+        const Fq y_nm = y.pow(nm), y_nm1 = y_nm * y;
+        Fq sum_y;
+        if (y_is_one) {
+            sum_y = Fq((uint64_t)nm);
+        } else {
+            sum_y = y * (y_nm - ONE) * inv_out[k + 1];
+        }
+        Fq sum_z, two_n_m1;  // sum_j z^(2(j+1)); 2^n - 1 = sum of the powers of two
+        for (int j = 0; j < m; j++) sum_z = sum_z + z2m[j];
+        for (size_t i = 0; i < n; i++) two_n_m1 = two_n_m1 + v2[i];
+        const Fq zeta = (z - zsq) * sum_y - z * y_nm1 * (two_n_m1 * sum_z);
+        jb.gen(iG, pf.w.r_prime * pf.w.s_prime * y - zeta * esq);  // g  :532-535
+        jb.gen(iH, pf.w.delta_prime);                              // h * delta'  :598
+        for (int j = 0; j < k; j++) jb.extra(pf.w.L[j], -(esq * xsq[k - 1 - j]));
+        for (int j = 0; j < k; j++) jb.extra(pf.w.R[j], -(esq * xisq[k - 1 - j]));
+        jb.extra(pf.A, -esq);  // P  :564-565
+        Fq mey = (-esq) * y_nm1;
+        for (int j = 0; j < m; j++) jb.extra(V[j], z2m[j] * mey);  // :568-571
+        jb.extra(pf.w.a_tag, -e);                                  // :574
+        Pt lhs;
+        RC(fbmsm(ctx, gens, jobs, &lhs, true));
+        *verdict = (lhs == pf.w.b_tag) ? BP_VERDICT_OK : BP_VERDICT_RANGE_PROOF_ERROR;  // :604
+        return BP_OK;
+    }
     PlusScalars ps = plus_common(n, m, y, z);
     WipChal c;
     if (!wip_challenges(pf.w, gn.Gh, gn.Hh, nm, y, c)) {
@@ -1573,28 +1669,6 @@ int bp_wip_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m
         return BP_OK;
     }
     const Fq e = c.e, esq = c.e * c.e;
-    if (mode == 2) {
-        // aggregated_verify (:388-609)
-        jobs.assign(1, FbJob());
-        FbJob& jb = jobs[0];
-        Fq er = pf.w.r_prime * e, es = pf.w.s_prime * e, esz = z * esq;
-        for (size_t i = 0; i < nm; i++) {
-            jb.gen(i, er * c.sg[i] + esz);                                                  // :540-545
-            jb.gen(nm + i, (es * c.sh[i] - esz) - ps.d[i] * ps.y_pow[nm - 1 - i] * esq);    // :549-557
-        }
-        jb.gen(iG, pf.w.r_prime * pf.w.s_prime * y - ps.zeta * esq);  // g  :532-535
-        jb.gen(iH, pf.w.delta_prime);                                 // h * delta'  :598
-        for (int j = 0; j < k; j++) jb.extra(pf.w.L[j], -(esq * c.x[j] * c.x[j]));
-        for (int j = 0; j < k; j++) jb.extra(pf.w.R[j], -(esq * c.xinv[j] * c.xinv[j]));
-        jb.extra(pf.A, -esq);  // P  :564-565
-        Fq mey = (-esq) * ps.y_nm1;
-        for (int j = 0; j < m; j++) jb.extra(V[j], ps.z2m[j] * mey);  // :568-571
-        jb.extra(pf.w.a_tag, -e);                                     // :574
-        Pt lhs;
-        RC(fbmsm(ctx, gens, jobs, &lhs, true));
-        *verdict = (lhs == pf.w.b_tag) ? BP_VERDICT_OK : BP_VERDICT_RANGE_PROOF_ERROR;  // :604
-        return BP_OK;
-    }
     // verify (:276-382): A_hat, then WeightedInnerProdArg::fast_verify (weighted_inner_product.rs:386-515)
     jobs.assign(2, FbJob());
     for (size_t i = 0; i < nm; i++) {  // A_hat  (:352-372)
