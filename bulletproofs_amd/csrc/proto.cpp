@@ -1039,6 +1039,126 @@ int bp_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint
     return BP_OK;
 }
 
+// RangeProof::aggregated_verify for one proof (range_proof.rs:537-782): ONE MSM - the 2 nm + 2 generator terms from the table,
+// the proof's points by ladders over tables that are built on the side stream meanwhile (FbPretab).  Host side arranged for
+// latency: y^-1 and (y - 1)^-1 (one exponentiation), x and c are computed during the y*G / x_u*G round trip; the x_j^-1 are one
+// more exponentiation; the generator scalars
+//   g_i : a s_i + z                                   :694-696
+//   h_i : y^-i (b s_(nm-1-i) - d_i) - z,  d_i = 2^(i mod n) z^(2 + i/n)      :699-705 (s_i^-1 = s_(nm-1-i))
+// come block by block from the host workers, every block stepping its running products s_i, s_(nm-1-i), y^-i by one
+// multiplication each (as in bp_wip_rangeproof_verify): 7 products per i instead of 11; sum_i y^i and sum_i d_i from closed forms.
+static int bp_verify_aggregated(bp_ctx* ctx, const bp_gens* gens, const Gens& gn, const BpProof& pf, const std::vector<Pt>& V, size_t n, int m, int k,
+                                uint8_t* verdict) {
+    const size_t nm = n * (size_t)m, iG = 2 * nm, iH = 2 * nm + 1;
+    const Fq ONE(1);
+    FbPretab pretab(ctx);
+    {  // the MSM's proof-specific points in the order the job lists them below
+        std::vector<Pt> xp;
+        xp.push_back(pf.S);
+        for (int j = 0; j < k; j++) xp.push_back(pf.ipa.L[j]);
+        for (int j = 0; j < k; j++) xp.push_back(pf.ipa.R[j]);
+        for (int j = 0; j < m; j++) xp.push_back(V[j]);
+        xp.push_back(pf.T1);
+        xp.push_back(pf.T2);
+        RC(pretab.begin(xp, tl_batcher != nullptr));
+    }
+    const Fq y = Transcript().point(pf.A.b).point(pf.S.b).result_scalar();                                                 // :565-567
+    const Fq xu = Transcript().bigint32(pf.tau_x_be).bigint32(pf.miu_be).bigint32(pf.tx_be).result_scalar();               // :581-585
+    std::vector<FbJob> jobs(2);
+    jobs[0].gen(gens->ibase, y);  // Point::generator() * y, not the caller's G   (:570-571)
+    jobs[1].gen(iG, xu);          // ux = G * x_u                                 (:588)
+    Fq x, cver, yinv, ym1inv;
+    const Fq ym1 = y - ONE;
+    const bool y_is_one = ym1.is_zero();
+    const std::function<void()> host_part = [&]() {
+        x = Transcript().point(pf.T1.b).point(pf.T2.b).point(gn.Gh.b).point(gn.Hh.b).result_scalar();                       // :576-578
+        cver = Transcript().point(pf.A.b).point(pf.S.b).point(pf.T1.b).point(pf.T2.b).point(gn.Gh.b).point(gn.Hh.b).result_scalar();  // :591-593
+        if (y.is_zero()) return;
+        std::vector<Fq> in(1, y), out;
+        if (!y_is_one) in.push_back(ym1);
+        batch_inv(in, out);
+        yinv = out[0];
+        if (!y_is_one) ym1inv = out[1];
+    };
+    Pt yGux[2];
+    RC(fbmsm(ctx, gens, jobs, yGux, false, &host_part));
+    const Pt &yG = yGux[0], &ux = yGux[1];
+    if (y.is_zero() || yG.is_inf() || ux.is_inf()) {
+        *verdict = BP_VERDICT_MALFORMED;
+        return BP_OK;
+    }
+    const Fq z = Transcript().point(yG.b).result_scalar();                                                                 // :573-574
+    std::vector<Fq> xs, xinv;
+    if (ipa_challenges(pf.ipa, ux, xs, xinv) != BP_OK) {
+        *verdict = BP_VERDICT_MALFORMED;
+        return BP_OK;
+    }
+    // bit b of i selects x_(k-1-b) (set) or its inverse (clear) in s_i (s_vector above); stepping i -> i + 1 clears the t
+    // trailing ones and sets bit t: ratio[t]; j -> j - 1 sets the t trailing zeros and clears bit t: iratio[t]
+    std::vector<Fq> xsq(k), xisq(k), ratio(k), iratio(k);
+    for (int b = 0; b < k; b++) {
+        xsq[b] = xs[k - 1 - b] * xs[k - 1 - b];
+        xisq[b] = xinv[k - 1 - b] * xinv[k - 1 - b];
+    }
+    {
+        Fq down = ONE, up = ONE;
+        for (int t = 0; t < k; t++) {
+            ratio[t] = xsq[t] * down;
+            iratio[t] = xisq[t] * up;
+            down = down * xisq[t];
+            up = up * xsq[t];
+        }
+    }
+    auto s_at = [&](size_t i) {
+        Fq p = ONE;
+        for (int b = 0; b < k; b++) p = p * (((i >> b) & 1) ? xs[k - 1 - b] : xinv[k - 1 - b]);
+        return p;
+    };
+    std::vector<Fq> v2(n), zpow(m);  // 2^r; z^(2+j)
+    v2[0] = ONE;
+    for (size_t i = 1; i < n; i++) v2[i] = v2[i - 1] + v2[i - 1];
+    zpow[0] = z * z;
+    for (int j = 1; j < m; j++) zpow[j] = zpow[j - 1] * z;
+    const Fq a = pf.ipa.a, b = pf.ipa.b;
+    jobs.assign(1, FbJob());
+    FbJob& jb = jobs[0];
+    job_slots(jb, 2 * nm);
+    host_blocks(nm, tl_batcher == nullptr, [&](size_t lo, size_t hi) {
+        Fq si = s_at(lo), sj = s_at(nm - 1 - lo), yv = yinv.pow(lo);
+        for (size_t i = lo; i < hi; i++) {
+            jb.gi[2 * i] = (uint32_t)i, jb.gs[2 * i] = si * a + z;
+            const Fq d = v2[i % n] * zpow[i / n];
+            jb.gi[2 * i + 1] = (uint32_t)(nm + i), jb.gs[2 * i + 1] = yv * (sj * b - d) - z;
+            if (i + 1 < hi) {
+                si = si * ratio[__builtin_ctzll(~(unsigned long long)i)];
+                sj = sj * iratio[__builtin_ctzll((unsigned long long)(nm - 1 - i))];
+                yv = yv * yinv;
+            }
+        }
+    });
+    // delta = (z - z^2) sum_i y^i - z sum_i d_i,  sum_i y^i = (y^nm - 1)/(y - 1),  sum_i d_i = (2^n - 1) sum_j z^(2+j)   :597-642
+    Fq sum_y, sum_z, two_n_m1;
+    if (y_is_one)
+        sum_y = Fq((uint64_t)nm);
+    else
+        sum_y = (y.pow(nm) - ONE) * ym1inv;
+    for (int j = 0; j < m; j++) sum_z = sum_z + zpow[j];
+    for (size_t i = 0; i < n; i++) two_n_m1 = two_n_m1 + v2[i];
+    const Fq delta = (z - z * z) * sum_y - (two_n_m1 * sum_z) * z;
+    jb.gen(iG, xu * (a * b - pf.tx) + cver * (delta - pf.tx));  // G  :708-719
+    jb.gen(iH, pf.miu - cver * pf.tau_x);                        // H  :722-723, 770
+    jb.extra(pf.S, -x);                                          // :727
+    for (int j = 0; j < k; j++) jb.extra(pf.ipa.L[j], -xsq[k - 1 - j]);   // :730
+    for (int j = 0; j < k; j++) jb.extra(pf.ipa.R[j], -xisq[k - 1 - j]);  // :731
+    for (int j = 0; j < m; j++) jb.extra(V[j], cver * zpow[j]);           // :734-736
+    jb.extra(pf.T1, cver * x);                                           // :739
+    jb.extra(pf.T2, cver * x * x);                                       // :740
+    Pt lhs;
+    RC(fbmsm(ctx, gens, jobs, &lhs, true));
+    *verdict = (lhs == pf.A) ? BP_VERDICT_OK : BP_VERDICT_RANGE_PROOF_ERROR;  // :777
+    return BP_OK;
+}
+
 // RangeProof::{verify (mode 0), fast_verify (mode 1), aggregated_verify (mode 2)}  (range_proof.rs:265-782)
 int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, const uint8_t* proof, size_t proof_len, const uint8_t* coms_xy,
                          int mode, uint8_t* verdict) {
@@ -1066,19 +1186,9 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
             return BP_OK;
         }
     }
+    if (mode == 2) return bp_verify_aggregated(ctx, gens, gn, pf, V, n, m, k, verdict);
     const Fq ONE(1), ZERO;
     const size_t iG = 2 * nm, iH = 2 * nm + 1;
-    FbPretab pretab(ctx);
-    if (mode == 2) {  // the MSM's proof-specific points in the order the job lists them below
-        std::vector<Pt> xp;
-        xp.push_back(pf.S);
-        for (int j = 0; j < k; j++) xp.push_back(pf.ipa.L[j]);
-        for (int j = 0; j < k; j++) xp.push_back(pf.ipa.R[j]);
-        for (int j = 0; j < m; j++) xp.push_back(V[j]);
-        xp.push_back(pf.T1);
-        xp.push_back(pf.T2);
-        RC(pretab.begin(xp, tl_batcher != nullptr));
-    }
     Fq y = Transcript().point(pf.A.b).point(pf.S.b).result_scalar();
     Fq xu = Transcript().bigint32(pf.tau_x_be).bigint32(pf.miu_be).bigint32(pf.tx_be).result_scalar();
     std::vector<FbJob> jobs(2);
@@ -1086,12 +1196,10 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
     jobs[1].gen(iG, xu);  // ux = G * x_u     (:657-658)
     Pt yGux[2];
     // what needs neither y*G nor ux is computed while the GPU works on them
-    Fq x, cver, sum_y, sum_2n;
+    Fq x, sum_y, sum_2n;
     std::vector<Fq> yi(nm), yinv(nm), vec_2n(n), zpow(m + 2);
     const std::function<void()> host_part = [&]() {
         x = Transcript().point(pf.T1.b).point(pf.T2.b).point(gn.Gh.b).point(gn.Hh.b).result_scalar();
-        if (mode == 2)
-            cver = Transcript().point(pf.A.b).point(pf.S.b).point(pf.T1.b).point(pf.T2.b).point(gn.Gh.b).point(gn.Hh.b).result_scalar();
         if (y.is_zero()) return;
         Fq yi1 = y.inv();
         yi[0] = yinv[0] = ONE;
@@ -1112,38 +1220,6 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
     }
     Fq z = Transcript().point(yG.b).result_scalar();
     for (int j = 0; j < m + 2; j++) zpow[j] = z.pow(2 + (uint64_t)j);
-
-    if (mode == 2) {
-        // aggregated_verify (:537-782): one MSM - generator terms from the table, proof points by GLV ladders
-        std::vector<Fq> xs, xinv;
-        if (ipa_challenges(pf.ipa, ux, xs, xinv) != BP_OK) {
-            *verdict = BP_VERDICT_MALFORMED;
-            return BP_OK;
-        }
-        std::vector<Fq> s = s_vector(xs, xinv, nm);
-        Fq sum_d;
-        jobs.assign(1, FbJob());
-        FbJob& jb = jobs[0];
-        for (size_t i = 0; i < nm; i++) {
-            Fq d = vec_2n[i % n] * zpow[i / n];
-            sum_d = sum_d + d;
-            jb.gen(i, s[i] * pf.ipa.a + z);                                  // :694-696
-            jb.gen(nm + i, yinv[i] * (s[nm - 1 - i] * pf.ipa.b - d) - z);    // :699-705 (s_i^-1 = s_{nm-1-i})
-        }
-        Fq delta = (z - z * z) * sum_y - sum_d * z;                                      // :639-642
-        jb.gen(iG, xu * (pf.ipa.a * pf.ipa.b - pf.tx) + cver * (delta - pf.tx));         // G  :708-719
-        jb.gen(iH, pf.miu - cver * pf.tau_x);                                            // H  :722-723, 770
-        jb.extra(pf.S, -x);
-        for (int j = 0; j < k; j++) jb.extra(pf.ipa.L[j], -(xs[j] * xs[j]));
-        for (int j = 0; j < k; j++) jb.extra(pf.ipa.R[j], -(xinv[j] * xinv[j]));
-        for (int j = 0; j < m; j++) jb.extra(V[j], cver * zpow[j]);
-        jb.extra(pf.T1, cver * x);
-        jb.extra(pf.T2, cver * x * x);
-        Pt lhs;
-        RC(fbmsm(ctx, gens, jobs, &lhs, true));
-        *verdict = (lhs == pf.A) ? BP_VERDICT_OK : BP_VERDICT_RANGE_PROOF_ERROR;  // :777
-        return BP_OK;
-    }
 
     // verify / fast_verify common part (:274-391 / :409-526); hi_tag_i = y^-i h_i enters through its scalar
     Fq zc2n;
