@@ -544,8 +544,8 @@ struct HostPool {
     }
 };
 template <class F>
-void host_blocks(size_t n, bool allow_threads, F fn) {
-    const size_t nthr = !allow_threads ? 1 : n >= 1024 ? 4 : n >= 512 ? 2 : 1;
+void host_blocks_n(size_t n, size_t nthr, F fn) {
+    if (nthr > n) nthr = n;
     if (nthr > 1) {
         static HostPool* pool = new HostPool();  // (thread-safe initialisation; leaked on purpose)
         std::unique_lock<std::mutex> lk(pool->use, std::try_to_lock);
@@ -555,6 +555,10 @@ void host_blocks(size_t n, bool allow_threads, F fn) {
         }
     }
     fn((size_t)0, n);
+}
+template <class F>
+void host_blocks(size_t n, bool allow_threads, F fn) {
+    host_blocks_n(n, !allow_threads ? 1 : n >= 1024 ? 4 : n >= 512 ? 2 : 1, fn);
 }
 // a job with one (generator index, scalar) slot per t < nm, filled by index (zero scalars stay: their digits add nothing)
 static void job_slots(FbJob& j, size_t nm) {
@@ -761,12 +765,26 @@ struct BpProof {
     uint8_t tau_x_be[32], miu_be[32], tx_be[32];
     Ipa ipa;
 };
+static bool decompress_all(const std::vector<std::pair<const uint8_t*, Pt*>>& dec) {
+    std::atomic<int> bad{0};
+    host_blocks_n(dec.size(), tl_batcher == nullptr && dec.size() >= 8 ? 4 : 1, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++)
+            if (!host_decompress(dec[i].first, dec[i].second->b)) bad.store(1);
+    });
+    return bad.load() == 0;
+}
 bool parse_bp(const uint8_t* pf, size_t len, int k, BpProof& out) {
     if (len != (size_t)292 + 66 * (size_t)k) return false;
     const uint8_t* q = pf;
-    Pt* pts[4] = {&out.A, &out.S, &out.T1, &out.T2};
-    for (int i = 0; i < 4; i++, q += 33)
-        if (!host_decompress(q, pts[i]->b)) return false;
+    // the 4 + 2k square roots (one exponentiation mod p each) on the host workers: they are what a single-proof verifier does
+    // before anything can start on the GPU
+    out.ipa.L.resize(k);
+    out.ipa.R.resize(k);
+    std::vector<std::pair<const uint8_t*, Pt*>> dec = {{pf, &out.A}, {pf + 33, &out.S}, {pf + 66, &out.T1}, {pf + 99, &out.T2}};
+    for (int j = 0; j < k; j++) dec.push_back({pf + 228 + 33 * j, &out.ipa.L[j]});
+    for (int j = 0; j < k; j++) dec.push_back({pf + 228 + 33 * (k + j), &out.ipa.R[j]});
+    if (!decompress_all(dec)) return false;
+    q += 4 * 33;
     for (int i = 0; i < 3; i++)
         if (!fq_be_is_canonical(q + 32 * i)) return false;
     memcpy(out.tau_x_be, q, 32);
@@ -775,13 +793,7 @@ bool parse_bp(const uint8_t* pf, size_t len, int k, BpProof& out) {
     out.tau_x = Fq::from_be(q);
     out.miu = Fq::from_be(q + 32);
     out.tx = Fq::from_be(q + 64);
-    q += 96;
-    out.ipa.L.resize(k);
-    out.ipa.R.resize(k);
-    for (int j = 0; j < k; j++, q += 33)
-        if (!host_decompress(q, out.ipa.L[j].b)) return false;
-    for (int j = 0; j < k; j++, q += 33)
-        if (!host_decompress(q, out.ipa.R[j].b)) return false;
+    q += 96 + 66 * (size_t)k;
     if (!fq_be_is_canonical(q) || !fq_be_is_canonical(q + 32)) return false;
     out.ipa.a = Fq::from_be(q);
     out.ipa.b = Fq::from_be(q + 32);
@@ -800,16 +812,15 @@ struct BpPlusProof {
 bool parse_bpplus(const uint8_t* pf, size_t len, int k, BpPlusProof& out) {
     if (len != (size_t)195 + 66 * (size_t)k) return false;
     const uint8_t* q = pf;
-    if (!host_decompress(q, out.A.b)) return false;
-    q += 33;
     out.w.L.resize(k);
     out.w.R.resize(k);
-    for (int j = 0; j < k; j++, q += 33)
-        if (!host_decompress(q, out.w.L[j].b)) return false;
-    for (int j = 0; j < k; j++, q += 33)
-        if (!host_decompress(q, out.w.R[j].b)) return false;
-    if (!host_decompress(q, out.w.a_tag.b) || !host_decompress(q + 33, out.w.b_tag.b)) return false;
-    q += 66;
+    std::vector<std::pair<const uint8_t*, Pt*>> dec = {{pf, &out.A}};
+    for (int j = 0; j < k; j++) dec.push_back({pf + 33 * (1 + j), &out.w.L[j]});
+    for (int j = 0; j < k; j++) dec.push_back({pf + 33 * (1 + k + j), &out.w.R[j]});
+    dec.push_back({pf + 33 * (1 + 2 * k), &out.w.a_tag});
+    dec.push_back({pf + 33 * (2 + 2 * k), &out.w.b_tag});
+    if (!decompress_all(dec)) return false;
+    q += 33 * (size_t)(3 + 2 * k);
     for (int i = 0; i < 3; i++)
         if (!fq_be_is_canonical(q + 32 * i)) return false;
     out.w.r_prime = Fq::from_be(q);
