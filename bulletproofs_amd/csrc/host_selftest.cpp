@@ -94,7 +94,7 @@ int bpt_fq_glv(uint8_t* k1, uint8_t* k2, const uint8_t* k) {
     return (n1 ? 1 : 0) | (n2 ? 2 : 0);
 }
 // host scalar class of the protocol layer (hostmath.h: 4 x 64-bit Montgomery limbs); op: 0 mul, 1 add, 2 sub, 3 inv(a),
-// 4 neg(a), 5 a^(low 64 bits of b), 6 ((a - b) * (a + b) + a) * b - a, 7 a == b (out[31])
+// 4 neg(a), 5 a^(low 64 bits of b), 6 ((a - b) * (a + b) + a) * b - a, 7 a == b (out[31]), 8 inv(a) by exponentiation
 void bpt_hostfq(uint8_t* out, const uint8_t* a, const uint8_t* b, int op) {
     Fq x = Fq::from_be(a), y = Fq::from_be(b), r;
     uint64_t e = 0;
@@ -107,6 +107,7 @@ void bpt_hostfq(uint8_t* out, const uint8_t* a, const uint8_t* b, int op) {
         case 4: r = -x; break;
         case 5: r = x.pow(e); break;
         case 6: r = ((x - y) * (x + y) + x) * y - x; break;
+        case 8: r = x.inv_fermat(); break;  // the exponentiation form (inv() runs division steps)
         default: r = Fq(x == y ? 1 : 0); break;
     }
     r.to_be(out);

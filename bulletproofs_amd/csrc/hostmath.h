@@ -137,9 +137,29 @@ struct Fq {
         for (int i = 0; i < n; i++) r = r * r;
         return r;
     }
+    // Inverse by Bernstein-Yang division steps (fp.h s30_inv_words with the modulus q, the code the device's fqm_inv_var runs):
+    // ~2 us on a host core against ~12 us for the exponentiation below, and a single-proof prover inverts one challenge per
+    // round between two GPU calls.  0 -> 0 (callers check for zero first: the reference unwraps).
+    Fq inv() const {
+        const uint64_t one[4] = {1, 0, 0, 0};
+        const uint64_t R2[4] = {0x896CF21467D7D140ULL, 0x741496C20E7CF878ULL, 0xE697F5E45BCD07C6ULL, 0x9D671CD581C69BC5ULL};
+        uint64_t plain[4];
+        mont_mul(plain, m, one);
+        uint32_t aw[8], rw[8];
+        for (int i = 0; i < 4; i++) {
+            aw[2 * i] = (uint32_t)plain[i];
+            aw[2 * i + 1] = (uint32_t)(plain[i] >> 32);
+        }
+        s30_inv_words<s30_mod_q>(aw, rw);
+        uint64_t r64[4];
+        for (int i = 0; i < 4; i++) r64[i] = (uint64_t)rw[2 * i] | ((uint64_t)rw[2 * i + 1] << 32);
+        Fq r;
+        mont_mul(r.m, r64, R2);
+        return r;
+    }
     // a^(q-2): the addition chain of fq_mont_inv (fq.h): 2^127 - 1 ones, then a sliding window over the low
     // 129 bits.  Caller guarantees non-zero (the reference unwraps).
-    Fq inv() const {
+    Fq inv_fermat() const {
         static const uint8_t nsqr[26] = {5, 3, 4, 4, 5, 2, 5, 6, 5, 4, 3, 6, 10, 4, 5, 4, 5, 6, 4, 5, 6, 10, 4, 9, 4, 1};
         static const uint8_t odd[26] = {11, 5, 5, 7, 13, 3, 7, 13, 11, 13, 1, 5, 7, 7, 15, 15, 9, 11, 13, 3, 13, 13, 9, 9, 15, 1};
         Fq tbl[8];

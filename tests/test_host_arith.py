@@ -224,7 +224,13 @@ def test_host_scalar_class(L):
         assert hf(a, 65537, 5) == pow(a, 65537, Q)
         assert hf(a, 2**64 - 1, 5) == pow(a, 2**64 - 1, Q)
         if a % Q:
-            assert hf(a, 0, 3) == pow(a, -1, Q)
+            assert hf(a, 0, 3) == pow(a, -1, Q)  # division steps (the protocol layer's inverse)
+            assert hf(a, 0, 8) == pow(a, -1, Q)  # the exponentiation it replaced
+        else:
+            assert hf(a, 0, 3) == 0
+    for _ in range(3000):  # the division-step inverse on many more values (variable number of rounds)
+        a = rng.randrange(1, Q)
+        assert hf(a, 0, 3) == pow(a, -1, Q)
 
 
 def test_ec(L, oracle_c):
