@@ -312,9 +312,12 @@ int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scal
     hipStream_t st = ctx->stream;
     int rc;
     if ((rc = ctx->wsum.reserve(72 * sizeof(xyzz))) != BP_OK) return rc;
-    if ((rc = ctx->result.reserve(sizeof(affine_mem) + 64)) != BP_OK) return rc;
+    if ((rc = ctx->result.reserve(sizeof(affine_mem) + 64 + sizeof(xyzz) + 16)) != BP_OK) return rc;
     affine_mem* d_res = (affine_mem*)ctx->result.p;
     uint8_t* d_res_be = (uint8_t*)ctx->result.p + sizeof(affine_mem);
+    const bool want_raw = ctx->msm_want_raw;
+    ctx->msm_want_raw = false;
+    ctx->msm_result_raw = false;
     if (n == 0) {
         // empty sum: result = init (or infinity)
         HIPCHK(hipMemsetAsync(ctx->wsum.p, 0, sizeof(xyzz), st), "memset");
@@ -329,7 +332,9 @@ int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scal
     }
     int c = 0, W = 0;
     if ((rc = msm_windows_on_device(ctx, d_points, d_scalars_be, n, 0, &c, &W)) != BP_OK) return rc;
-    HIPCHK(launch_msm_horner((const xyzz*)ctx->wsum.p, W, c, d_init, d_res, d_res_be, st), "horner");
+    xyzz* d_raw = (xyzz*)(d_res_be + 64);
+    HIPCHK(launch_msm_horner((const xyzz*)ctx->wsum.p, W, c, d_init, d_res, d_res_be, st, want_raw ? d_raw : nullptr, ctx->d_err), "horner");
+    ctx->msm_result_raw = want_raw;
     return BP_OK;
 }
 
@@ -348,6 +353,21 @@ static int upload_init(bp_ctx* ctx, const uint8_t* init_xy, const affine_mem** d
 
 int msm_fetch_result(bp_ctx* ctx, uint8_t out_xy[64]) {
     int h_err = 0;
+    if (ctx->msm_result_raw) {  // XYZZ sum + flag, one copy; the inversion on the host (ec.h: the code k_msm_horner runs otherwise)
+        ctx->msm_result_raw = false;
+        uint8_t raw[sizeof(xyzz) + sizeof(int)];
+        HIPCHK(hipMemcpyAsync(raw, (uint8_t*)ctx->result.p + sizeof(affine_mem) + 64, sizeof(raw), hipMemcpyDeviceToHost, ctx->stream), "memcpy out");
+        HIPCHK(hipStreamSynchronize(ctx->stream), "sync");
+        memcpy(&h_err, raw + sizeof(xyzz), sizeof(int));
+        if (h_err) {
+            set_error_msg("input point not on curve");
+            return BP_EPOINT;
+        }
+        xyzz sum;
+        memcpy(&sum, raw, sizeof(xyzz));
+        affine_to_be64(out_xy, xyzz_to_affine_var(sum));
+        return BP_OK;
+    }
     uint8_t tmp[64];
     HIPCHK(hipMemcpyAsync(tmp, (uint8_t*)ctx->result.p + sizeof(affine_mem), 64, hipMemcpyDeviceToHost, ctx->stream), "memcpy out");
     HIPCHK(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), "memcpy err");
@@ -472,6 +492,7 @@ int bp_msm_device(bp_ctx* ctx, const void* d_points_xy, const void* d_scalars_be
     HIPCHK(launch_ingest_points((const uint8_t*)d_points_xy, (affine_mem*)ctx->points.p, n, ctx->d_err, ctx->stream), "ingest");
     const affine_mem* d_init;
     if ((rc = upload_init(ctx, init_xy, &d_init)) != BP_OK) return rc;
+    ctx->msm_want_raw = true;
     if ((rc = msm_on_device(ctx, (const affine_mem*)ctx->points.p, (const uint8_t*)d_scalars_be, n, d_init)) != BP_OK) return rc;
     return msm_fetch_result(ctx, out_xy);
 }

@@ -39,6 +39,9 @@ struct bp_ctx {
     int* d_err = nullptr;  // [0] input-validation flag of the current call, [1] parked flag of bp_msm_partial_device_out
     bool async_point_check = false;  // d_err[1] is pending: bp_ctx_sync / bp_msm_combine_device report it
     int forced_c = 0;
+    // large MSMs whose result the host reads (bp_msm, bp_msm_device): msm_want_raw asks msm_on_device for the XYZZ sum + flag in
+    // one buffer (k_msm_horner's out_raw), msm_result_raw says the last call delivered it that way (msm_fetch_result)
+    bool msm_want_raw = false, msm_result_raw = false;
     int ncu = 0;  // compute units of the device (window-group launches are sized per CU)
     int msm_path = 0;  // 0 auto, 1 LDS slice path, 2 sorted path (bp_msm_set_path)
     int msm_pipeline = 0;  // 0 = window groups on side streams from 2^19 points (lowest latency of one call), 1 = one group, 2 = groups from 2^16 points (bp_msm_set_pipeline)

@@ -38,7 +38,8 @@ size_t msm_tiny_scratch_bytes();
 hipError_t launch_msm_tiny(const affine_mem* pts, const uint8_t* scalars_be, size_t n, const affine_mem* init, xyzz* tabs, affine_mem* out_limbs,
                            uint8_t* out_be, hipStream_t st);
 hipError_t launch_or_flag(int* dst, const int* src, hipStream_t st);
-hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine_mem* init, affine_mem* out_limbs, uint8_t* out_be, hipStream_t st);
+hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine_mem* init, affine_mem* out_limbs, uint8_t* out_be, hipStream_t st,
+                             xyzz* out_raw = nullptr, const int* err_in = nullptr);
 
 
 // msm_sorted.hip: large-N path (global counting sort by bucket, balanced segment accumulation)

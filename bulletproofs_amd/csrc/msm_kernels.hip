@@ -333,8 +333,11 @@ hipError_t launch_msm_tiny(const affine_mem* pts, const uint8_t* scalars_be, siz
 
 // result = init + sum_w 2^(c*w) wsum[w]  (Horner, one quad of lanes sharing every point operation, ecq.h: the doubling
 // chain is inherently serial), normalised to the canonical affine element and written as 64 big-endian bytes.
+// out_raw != nullptr (callers that read the result on the host: bp_msm, bp_msm_device): the XYZZ sum and the input-validation
+// flag in ONE buffer - the host does the inversion with the same ec.h code (45 us of a lone lane here, 2 us there) and fetches
+// sum and flag with one copy instead of two.
 __global__ __launch_bounds__(64) void k_msm_horner(const xyzz* __restrict__ wsum, int W, int c, const affine_mem* __restrict__ init, affine_mem* __restrict__ out_limbs,
-                             uint8_t* __restrict__ out_be) {
+                             uint8_t* __restrict__ out_be, xyzz* __restrict__ out_raw, const int* __restrict__ err_in) {
     if (threadIdx.x >= 4 || blockIdx.x != 0) return;
     __builtin_amdgcn_s_setprio(3);
     const int q = threadIdx.x;
@@ -346,6 +349,11 @@ __global__ __launch_bounds__(64) void k_msm_horner(const xyzz* __restrict__ wsum
     }
     if (q != 0) return;
     if (init) xyzz_madd(acc, affine_load(*init));
+    if (out_raw) {
+        out_raw[0] = acc;
+        *reinterpret_cast<int*>(out_raw + 1) = *err_in;
+        return;
+    }
     affine_mem m = affine_store(xyzz_to_affine_var(acc));
     if (out_limbs) *out_limbs = m;
     if (out_be) {
@@ -417,8 +425,9 @@ hipError_t launch_msm_reduce_parts(const xyzz* parts, int G, int W, xyzz* wsum, 
     hipLaunchKernelGGL(k_msm_reduce_parts, dim3((unsigned)W), dim3(64), 0, st, parts, G, W, wsum);
     return hipGetLastError();
 }
-hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine_mem* init, affine_mem* out_limbs, uint8_t* out_be, hipStream_t st) {
-    hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(64), 0, st, wsum, W, c, init, out_limbs, out_be);
+hipError_t launch_msm_horner(const xyzz* wsum, int W, int c, const affine_mem* init, affine_mem* out_limbs, uint8_t* out_be, hipStream_t st,
+                             xyzz* out_raw, const int* err_in) {
+    hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(64), 0, st, wsum, W, c, init, out_limbs, out_be, out_raw, err_in);
     return hipGetLastError();
 }
 
