@@ -193,7 +193,7 @@ static int plan_window_groups(int W, int* gsz, size_t n2) {
 // want_c = 0: planner's choice (and its choice of path); otherwise the sorted path with that width.
 // Path: GLV split (2n virtual points, 129-bit scalars) -> LDS slice path (tiny n) or global sorted path.
 static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scalars_be, size_t n, int want_c, int* c_out,
-                                 int* W_out) {
+                                 int* W_out, bool full_msm = false) {
     hipStream_t st = ctx->stream;
     int rc;
     if ((rc = ctx->wsum.reserve(72 * sizeof(xyzz))) != BP_OK) return rc;
@@ -297,6 +297,7 @@ static int msm_windows_on_device(bp_ctx* ctx, const affine_mem* d_points, const 
             HIPCHK(launch_glv_digits(d_scalars_be, n, pl.npad, pl.c, pl.W, (int16_t*)ctx->digits.p, st), "digits");
         }
         pl.ncu = ctx->ncu;
+        pl.weighted = full_msm && ng <= 1;  // (partials for another rank's combine stay plain window sums)
         int c_eff = pl.c;
         HIPCHK(launch_msm_sorted(d_points, lam, n, (const int16_t*)ctx->digits.p, n2, pl, b, (xyzz*)ctx->wsum.p, st, ctx->srt_streams, gsz, ng, W_out,
                                  &c_eff),
@@ -331,7 +332,7 @@ int msm_on_device(bp_ctx* ctx, const affine_mem* d_points, const uint8_t* d_scal
         return BP_OK;
     }
     int c = 0, W = 0;
-    if ((rc = msm_windows_on_device(ctx, d_points, d_scalars_be, n, 0, &c, &W)) != BP_OK) return rc;
+    if ((rc = msm_windows_on_device(ctx, d_points, d_scalars_be, n, 0, &c, &W, true)) != BP_OK) return rc;
     xyzz* d_raw = (xyzz*)(d_res_be + 64);
     HIPCHK(launch_msm_horner((const xyzz*)ctx->wsum.p, W, c, d_init, d_res, d_res_be, st, want_raw ? d_raw : nullptr, ctx->d_err), "horner");
     ctx->msm_result_raw = want_raw;

@@ -48,6 +48,7 @@ struct SortedPlan {
     int Lmin, pstride;  // shortest segment a window group may use (launch_msm_sorted) and the stride of Pseg it implies
     int ncu;  // compute units of the device (0 = unknown)
     int sort2 = 0;  // 1 = two-pass sort at any size (bp_msm_set_path(ctx, 3): tests), 0 = from 2^15 virtual points
+    int weighted = 0;  // 1 = one-group path: window w's workgroup also multiplies its sum by 2^(c w) (full MSMs only, see k_srt_window)
     size_t npad;
 };
 struct SortedBufs {

@@ -558,8 +558,11 @@ __device__ __forceinline__ void srt_grid(const uint32_t* __restrict__ bs, int NB
 //   scan    suf_k = sum_(k' >= k) s_k'                                          5 levels
 //   V_k = w_k + per * suf_k (k >= 1)   ->  sum_k V_k = sum_e e X_e;  rows: V_k <- LO * V_k, and V_0 += suf_0 = sum_hi R_hi
 //   tree over the 64 V_k                                                        6 levels
+// dbl_c > 0 (one window group, full MSM): the workgroup of window w goes on to 2^(dbl_c w) times its sum, so that the windows'
+// doubling chains run side by side - the longest, c (W - 1) doublings, is the Horner chain's length minus one window - and
+// k_msm_horner only adds the W results (2^16 points: k_msm_horner 312 us -> the top window's 290 us inside this kernel).
 __global__ __launch_bounds__(256) void k_srt_window(const uint32_t* __restrict__ bstart, const xyzz* __restrict__ RC, int NB, int lo_bits, int w0,
-                                                       xyzz* __restrict__ wsum) {
+                                                       xyzz* __restrict__ wsum, int dbl_c) {
     __shared__ xyzz red[64];
     __builtin_amdgcn_s_setprio(3);  // latency-bound: issue ahead of the co-resident accumulation waves
     const int lq = threadIdx.x >> 2, q = threadIdx.x & 3, w = w0 + blockIdx.x;
@@ -619,7 +622,14 @@ __global__ __launch_bounds__(256) void k_srt_window(const uint32_t* __restrict__
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) wsum[w] = red[0];
+    if (dbl_c > 0 && w > 0) {
+        if (threadIdx.x < 4) {  // quad 0
+            const xyzz r = xyzzq_dbl_n(q, red[0], dbl_c * w);
+            if (q == 0) wsum[w] = r;
+        }
+    } else if (threadIdx.x == 0) {
+        wsum[w] = red[0];
+    }
 }
 
 // wsum[w_lo] = sum_{w_lo <= w < w_hi} 2^(c (w - w_lo)) wsum[w]  (+ wsum[vidx] when vidx >= 0: the combination of the
@@ -790,7 +800,8 @@ static void srt_acc_windows(const affine_mem* pts, const affine_mem* lam, size_t
                        pl.pstride, w0, nw, b.Bk, b.Pseg);
 }
 // bucket reduction of the windows [w0, w0 + nw): wsum[w] = sum_b (b+1) bucket_w[b]
-static hipError_t srt_reduce_windows(const SortedPlan& pl, const SortedBufs& b, int w0, int nw, int L, xyzz* wsum, hipStream_t st, bool lat) {
+static hipError_t srt_reduce_windows(const SortedPlan& pl, const SortedBufs& b, int w0, int nw, int L, xyzz* wsum, hipStream_t st, bool lat,
+                                     int dbl_c = 0) {
     const int NB = pl.NB;
     const int nout = (1 << pl.lo_bits) + (NB >> pl.lo_bits);
     // 64 QUADS per output that share every addition (ecq.h), 256-lane workgroups (rowcol2 for one window 142 -> 58 us).  For the
@@ -810,7 +821,7 @@ static hipError_t srt_reduce_windows(const SortedPlan& pl, const SortedBufs& b, 
     else
         hipLaunchKernelGGL(k_srt_rowcol2<1>, dim3((unsigned)nout, (unsigned)nw), dim3(64), (size_t)64 * sizeof(xyzz), st, b.bstart, b.Bk, b.Pseg, NB, L,
                            pl.pstride, pl.lo_bits, w0, b.RC);
-    hipLaunchKernelGGL(k_srt_window, dim3((unsigned)nw), dim3(256), 0, st, b.bstart, b.RC, NB, pl.lo_bits, w0, wsum);
+    hipLaunchKernelGGL(k_srt_window, dim3((unsigned)nw), dim3(256), 0, st, b.bstart, b.RC, NB, pl.lo_bits, w0, wsum, dbl_c);
     return hipGetLastError();
 }
 
@@ -834,7 +845,8 @@ hipError_t launch_msm_sorted(const affine_mem* pts, const affine_mem* lam, size_
         srt_sort_windows(digits, n2, pl, b, 0, W, st);
         srt_acc_windows(pts, lam, n1, pl, b, 0, W, pl.L, pl.nseg, st);
         *W_eff = W;
-        return srt_reduce_windows(pl, b, 0, W, pl.L, wsum, st, true);
+        if (pl.weighted) *c_eff = 0;  // the window sums come back multiplied by their 2^(c w): the caller only adds them
+        return srt_reduce_windows(pl, b, 0, W, pl.L, wsum, st, true, pl.weighted ? pl.c : 0);
     }
     // Segment length per group: an accumulation launch should fill the chip's resident slots about once (k_srt_acc: three
     // 256-lane workgroups per CU) - a launch of 1.67 "rounds" runs its last round two thirds empty, a launch of a third of a
