@@ -7,6 +7,8 @@ log2 = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 N = 1 << log2
 ctx = bpa.Context(0)
+if os.environ.get("PIPELINE"):  # bp_msm_set_pipeline: 0 = groups from 2^19 points (default), 1 = one group, 2 = groups from 2^16 points
+    ctx.set_msm_pipeline(int(os.environ["PIPELINE"]))
 def stream(tag, count, start):
     return b"".join(hashlib.sha256(b"bpmsm-c5-%s-%d" % (tag, i)).digest() for i in range(start, start + count))
 pts = bytearray()

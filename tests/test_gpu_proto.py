@@ -329,3 +329,52 @@ def test_caller_G_different_from_the_curve_generator(ctx, oracle_c, kind):
             ctx.set_proto_path(0)
     finally:
         gens.close()
+
+
+def test_single_proof_calls_from_several_threads(ctx):
+    """The single-proof calls' host side (round 3): window tables of the proof's points on the side stream, scalars and
+    decompressions on the process-wide host workers.  Four contexts on four threads prove and verify the n=64 m=16 fixture
+    (n*m = 1024: the size from which the workers are used; a second caller's pass runs inline) at once; bytes and verdicts
+    as the fixture's; then the first context's calls again in a different order, a batch call between them (its workspaces and
+    the side stream are shared with the single-proof path)."""
+    import threading
+
+    case = load("bp_c2_n64_m16.json")
+    n, m = case["n"], case["m"]
+    g, h, G, H = bpa.generate_bases(0, bpa.KZEN_SEED, n, m)
+    proof, coms = bytes.fromhex(case["proof"]), b"".join(bytes.fromhex(c) for c in case["commitments"])
+    sec, bl, tape = _be(case["secrets"]), _be(case["blindings"]), bytes.fromhex(case["tape"])
+    bad = bytearray(proof)
+    bad[-1] ^= 1  # b of the inner-product argument: RangeProofError
+    ctxs = [ctx] + [bpa.Context(0) for _ in range(3)]
+    gens = [bpa.Gens(c, g, h, G, H, 8) for c in ctxs]
+    errs = []
+
+    def work(i):
+        try:
+            c, gn = ctxs[i], gens[i]
+            for rep in range(3):
+                assert c.rangeproof_verify(gn, n, m, proof, coms, 2) == VERDICT_CODE["Ok"]
+                assert c.rangeproof_verify(gn, n, m, bytes(bad), coms, 2) == VERDICT_CODE["RangeProofError"]
+                if (i + rep) % 2 == 0:
+                    assert c.rangeproof_prove(gn, n, sec, bl, tape).hex() == case["proof"]
+                assert c.rangeproof_verify(gn, n, m, proof, coms, 1) == VERDICT_CODE["Ok"]
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errs.append((i, repr(e)))
+
+    thr = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in thr:
+        t.start()
+    for t in thr:
+        t.join()
+    try:
+        assert not errs, errs
+        assert ctx.rangeproof_verify(gens[0], n, m, bytes(bad), coms, 2) == VERDICT_CODE["RangeProofError"]
+        v = ctx.rangeproof_verify_batch(gens[0], n, m, proof + bytes(bad) + proof, coms * 3)
+        assert list(v) == [VERDICT_CODE["Ok"], VERDICT_CODE["RangeProofError"], VERDICT_CODE["Ok"]]
+        assert ctx.rangeproof_verify(gens[0], n, m, proof, coms, 2) == VERDICT_CODE["Ok"]
+    finally:
+        for gn in gens:
+            gn.close()
+        for c in ctxs[1:]:
+            c.close()
