@@ -180,7 +180,7 @@ int pin_reserve(bp_ctx* ctx, size_t bytes) {
 }
 
 // Single-proof verifiers: the window tables of the proof's points (the scalar-independent half of their ladders: the top slices'
-// 68 base doublings and the 8-entry tables, ~0.2 ms of one workgroup) start on the context's side stream as soon as the proof is
+// 88 base doublings and the 8-entry tables, ~0.25 ms of one workgroup) start on the context's side stream as soon as the proof is
 // parsed and run beside the transcript hashes, the y*G round trip and the host's scalar vector; the ONE-job MSM that follows
 // (use_pre) waits for them and runs the ladders only.  The guard orders ctx->stream after the table
 // kernel on every exit path, so that nothing later on that stream touches ctx->vartab while it is still being written.
