@@ -100,6 +100,8 @@ struct bp_ctx {
     void* h_fbpre = nullptr;                               // pinned staging of the points (64 KiB, allocated at first use)
     hipEvent_t ev_fbpre = nullptr, ev_fbpre0 = nullptr;    // tables built (side stream) / ctx->stream's earlier work done
     int fbpre_n = 0;  // points whose tables are pending in ctx->vartab (0 = none)
+    int fbpre_nj = 0;               // ... of this many jobs,
+    uint32_t fbpre_off[9] = {};     // job j owning points fbpre_off[j] .. fbpre_off[j + 1)
     void* h_pin = nullptr;  // pinned host staging for the protocol layer's small uploads / read-backs (grow-only)
     size_t h_pin_cap = 0;
     void release_all() {

@@ -96,10 +96,14 @@ __global__ __launch_bounds__(FB_T) void k_fb_final(const xyzz* __restrict__ part
 // when the scalars are - measured on C1: two ranges 199 us of tables (hidden) + 298 us of ladders, four ranges 361 us (73 us of them
 // exposed) + 179 us, three ranges 88 doublings in the tables and 44 doublings + 11 additions in a ladder.  The single-proof verifiers know their proof's points before they know the scalars (two transcript
 // hashes, a fixed-base round trip and the whole scalar vector lie in between): the tables are built on the side stream meanwhile.
-__global__ __launch_bounds__(FB_T) void k_fb_pretab(const uint8_t* __restrict__ xbe, int nx, xyzz* __restrict__ vartab) {
-    const int L = blockIdx.x * FB_T + threadIdx.x, p = L / (2 * FB_PRE_PARTS), slice = L % (2 * FB_PRE_PARTS);
-    if (p >= nx) return;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(xbe + 64 * (size_t)p);
+// Several jobs (the verify / fast_verify calls: eq. 65's right side, P, the inner-product check): blockIdx.y = job, whose points
+// are xbe[off[job] .. off[job + 1]) and whose lanes start at block job * gridDim.x, as in k_fb_acc.
+__global__ __launch_bounds__(FB_T) void k_fb_pretab(const uint8_t* __restrict__ xbe, FbPreJobs jobs, xyzz* __restrict__ vartab) {
+    const int job = blockIdx.y;
+    const int L = blockIdx.x * FB_T + threadIdx.x, pl = L / (2 * FB_PRE_PARTS), slice = L % (2 * FB_PRE_PARTS);
+    if (pl >= (int)(jobs.off[job + 1] - jobs.off[job])) return;
+    const size_t p = jobs.off[job] + (size_t)pl;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(xbe + 64 * p);
     affine_mem m;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -107,11 +111,11 @@ __global__ __launch_bounds__(FB_T) void k_fb_pretab(const uint8_t* __restrict__ 
         m.y.w[k] = __builtin_bswap32(src[15 - k]);
     }
     if (!affine_mem_valid(m, false)) return;  // infinity / not on the curve: the call itself skips or rejects the point
-    ec_slice_table(affine_load(m), slice, vartab + (size_t)L * ECMUL_NT, FB_PRE_PARTS);
+    ec_slice_table(affine_load(m), slice, vartab + (((size_t)job * gridDim.x + blockIdx.x) * FB_T + threadIdx.x) * ECMUL_NT, FB_PRE_PARTS);
 }
-hipError_t launch_fb_pretab(const uint8_t* xbe, int nx, xyzz* vartab, hipStream_t st) {
-    if (nx <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_fb_pretab, dim3((unsigned)((2 * FB_PRE_PARTS * nx + FB_T - 1) / FB_T)), dim3(FB_T), 0, st, xbe, nx, vartab);
+hipError_t launch_fb_pretab(const uint8_t* xbe, const FbPreJobs& jobs, int nj, int nxblk, xyzz* vartab, hipStream_t st) {
+    if (nj <= 0 || nxblk <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fb_pretab, dim3((unsigned)nxblk, (unsigned)nj), dim3(FB_T), 0, st, xbe, jobs, vartab);
     return hipGetLastError();
 }
 

@@ -160,7 +160,10 @@ hipError_t launch_fb_msm(size_t njobs, const affine_mem* table, int W, int NB, c
                          const affine_mem* xpts, const uint8_t* xsc_be, const uint32_t* xoff, int nblk, int nxblk, xyzz* vartab, xyzz* partial,
                          uint8_t* out_be, hipStream_t st, int pre = 0, xyzz* out_raw = nullptr);
 #define FB_PRE_PARTS 3  // window ranges per GLV half of the tables k_fb_pretab builds (launch_fb_msm's `pre`)
-hipError_t launch_fb_pretab(const uint8_t* xbe, int nx, xyzz* vartab, hipStream_t st);
+struct FbPreJobs {  // point ranges of up to 8 jobs: job j owns points off[j] .. off[j + 1)
+    uint32_t off[9];
+};
+hipError_t launch_fb_pretab(const uint8_t* xbe, const FbPreJobs& jobs, int nj, int nxblk, xyzz* vartab, hipStream_t st);
 
 // ecbatch_kernels.hip
 size_t ecbatch_vartab_bytes(size_t n);

@@ -187,9 +187,21 @@ int pin_reserve(bp_ctx* ctx, size_t bytes) {
 struct FbPretab {
     bp_ctx* ctx;
     explicit FbPretab(bp_ctx* c) : ctx(c) {}
-    int begin(const std::vector<Pt>& pts, bool batched) {
+    int begin(const std::vector<Pt>& pts, bool batched) { return begin(pts, std::vector<size_t>(1, pts.size()), batched); }
+    // several jobs: `pts` holds job 0's points, then job 1's, ...; counts[j] of them each (a job without points: 0)
+    int begin(const std::vector<Pt>& pts, const std::vector<size_t>& counts, bool batched) {
         const int nx = (int)pts.size();
-        if (batched || nx == 0 || nx > 1024) return BP_OK;  // (a batch prover's rendezvous merges jobs: its layout is not this one)
+        const int nj = (int)counts.size();
+        if (batched || nx == 0 || nx > 1024 || nj < 1 || nj > 8) return BP_OK;  // (a batch prover's rendezvous merges jobs: its layout is not this one)
+        size_t max_x = 0, tot = 0;
+        FbPreJobs pj;
+        for (int j = 0; j < nj; j++) {
+            pj.off[j] = (uint32_t)tot;
+            tot += counts[j];
+            if (counts[j] > max_x) max_x = counts[j];
+        }
+        for (int j = nj; j < 9; j++) pj.off[j] = (uint32_t)tot;
+        if (tot != (size_t)nx) return BP_EINVAL;
         hipStream_t side;
         HIPCHK(ctx->side_stream(&side), "hipStreamCreate");
         if (!ctx->ev_fbpre) {
@@ -199,17 +211,19 @@ struct FbPretab {
         } else {
             HIPCHK(hipEventSynchronize(ctx->ev_fbpre), "event sync");  // the previous call's upload has left the staging buffer
         }
-        const int nxblk = (2 * FB_PRE_PARTS * nx + 255) / 256;
-        RC(ctx->vartab.reserve(fb_vartab_bytes(1, nxblk)));
+        const int nxblk = (int)((2 * FB_PRE_PARTS * max_x + 255) / 256);
+        RC(ctx->vartab.reserve(fb_vartab_bytes((size_t)nj, nxblk)));
         RC(ctx->fbpre.reserve((size_t)nx * 64));
         memcpy(ctx->h_fbpre, pts.data(), (size_t)nx * 64);
         // ctx->vartab is free once everything queued on ctx->stream has run
         HIPCHK(hipEventRecord(ctx->ev_fbpre0, ctx->stream), "record event");
         HIPCHK(hipStreamWaitEvent(side, ctx->ev_fbpre0, 0), "wait event");
         HIPCHK(hipMemcpyAsync(ctx->fbpre.p, ctx->h_fbpre, (size_t)nx * 64, hipMemcpyHostToDevice, side), "h2d");
-        HIPCHK(launch_fb_pretab((const uint8_t*)ctx->fbpre.p, nx, (xyzz*)ctx->vartab.p, side), "fb_pretab");
+        HIPCHK(launch_fb_pretab((const uint8_t*)ctx->fbpre.p, pj, nj, nxblk, (xyzz*)ctx->vartab.p, side), "fb_pretab");
         HIPCHK(hipEventRecord(ctx->ev_fbpre, side), "record event");
         ctx->fbpre_n = nx;
+        ctx->fbpre_nj = nj;
+        memcpy(ctx->fbpre_off, pj.off, sizeof(pj.off));
         return BP_OK;
     }
     ~FbPretab() {
@@ -246,7 +260,8 @@ int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_i
     if (nblk < 1) nblk = 1;
     if (nblk > 128) nblk = 128;
     // the window tables of exactly these points, in this order, are being built (FbPretab): 2 FB_PRE_PARTS lanes per point
-    const bool pre_ok = use_pre && ctx->fbpre_n && nj == 1 && nx == (size_t)ctx->fbpre_n;
+    bool pre_ok = use_pre && ctx->fbpre_n && nj == (size_t)ctx->fbpre_nj && nx == (size_t)ctx->fbpre_n;
+    for (size_t j = 0; pre_ok && j < nj; j++) pre_ok = jobs[j].xp.size() == (size_t)(ctx->fbpre_off[j + 1] - ctx->fbpre_off[j]);
     const int nxblk = (int)(((pre_ok ? 2 * FB_PRE_PARTS : 4) * max_x + 255) / 256);  // else four lanes per job-specific point (ec_mul_glv_slice)
     if (nxblk > 64 || nt >= ((size_t)1 << 31) || nx >= ((size_t)1 << 31)) {
         set_error_msg("internal: fixed-table MSM job too large");
@@ -295,6 +310,9 @@ int fbmsm_direct(bp_ctx* ctx, const bp_gens* g, const std::vector<FbJob>& jobs_i
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_fbpre, 0), "wait event");
         ctx->fbpre_n = 0;
         pre = FB_PRE_PARTS;
+    } else if (ctx->fbpre_n && nxblk) {  // tables pending that this call does not use: it writes ctx->vartab itself, after them
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_fbpre, 0), "wait event");
+        ctx->fbpre_n = 0;
     }
     uint8_t* d = (uint8_t*)ctx->fb[0].p;
     affine_mem* d_xpts = (affine_mem*)(d + o_xpts);
@@ -1200,6 +1218,27 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
     if (mode == 2) return bp_verify_aggregated(ctx, gens, gn, pf, V, n, m, k, verdict);
     const Fq ONE(1), ZERO;
     const size_t iG = 2 * nm, iH = 2 * nm + 1;
+    // the job-specific points of the MSM call below, job by job in the order the jobs list them: their window tables are built
+    // on the side stream while the host derives the scalars (FbPretab)
+    FbPretab pretab(ctx);
+    {
+        std::vector<Pt> xp;
+        std::vector<size_t> cnt;
+        cnt.push_back(0);  // eq. 65, left: generators only
+        for (int j = 0; j < m; j++) xp.push_back(V[j]);
+        xp.push_back(pf.T1);
+        xp.push_back(pf.T2);
+        cnt.push_back((size_t)m + 2);
+        xp.push_back(pf.A);
+        xp.push_back(pf.S);
+        cnt.push_back(2);
+        if (mode == 1) {
+            for (int j = 0; j < k; j++) xp.push_back(pf.ipa.L[j]);
+            for (int j = 0; j < k; j++) xp.push_back(pf.ipa.R[j]);
+            cnt.push_back(2 * (size_t)k);
+        }
+        RC(pretab.begin(xp, cnt, tl_batcher != nullptr));
+    }
     Fq y = Transcript().point(pf.A.b).point(pf.S.b).result_scalar();
     Fq xu = Transcript().bigint32(pf.tau_x_be).bigint32(pf.miu_be).bigint32(pf.tx_be).result_scalar();
     std::vector<FbJob> jobs(2);
@@ -1269,7 +1308,7 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
         }
     }
     Pt res[4];
-    RC(fbmsm(ctx, gens, jobs, res));
+    RC(fbmsm(ctx, gens, jobs, res, true));
     const Pt &left = res[0], &right = res[1], &P = res[2];
     if (mode == 1) {
         ok = chal_ok && res[3] == P;
