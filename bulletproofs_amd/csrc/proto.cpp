@@ -686,14 +686,17 @@ int ipa_challenges(const Ipa& p, const Pt& ux, std::vector<Fq>& x, std::vector<F
 }
 std::vector<Fq> s_vector(const std::vector<Fq>& x, const std::vector<Fq>& xinv, size_t n) {
     size_t k = x.size();
-    std::vector<Fq> s(n);
+    std::vector<Fq> s(n), xsq(k);
     Fq allinv(1);
-    for (size_t j = 0; j < k; j++) allinv = allinv * xinv[j];
+    for (size_t j = 0; j < k; j++) {
+        allinv = allinv * xinv[j];
+        xsq[j] = x[j] * x[j];
+    }
     s[0] = allinv;
     for (size_t i = 1; i < n; i++) {
         int lg = 0;
         while (((size_t)2 << lg) <= i) lg++;
-        s[i] = s[i - ((size_t)1 << lg)] * x[(k - 1) - lg] * x[(k - 1) - lg];
+        s[i] = s[i - ((size_t)1 << lg)] * xsq[(k - 1) - lg];
     }
     return s;
 }
@@ -1283,10 +1286,15 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
     jobs[1].extra(pf.T1, x);
     jobs[1].extra(pf.T2, x * x);
     // P = -miu H + tx Gx + A + x S + sum (z y^i + z^(2+j) 2^k) hi_tag_i - z sum g_i   (:361-391)
-    for (size_t i = 0; i < nm; i++) {
-        jobs[2].gen(nm + i, (z * yi[i] + zpow[i / n] * vec_2n[i % n]) * yinv[i]);
-        jobs[2].gen(i, -z);
-    }
+    const bool workers = tl_batcher == nullptr;
+    job_slots(jobs[2], 2 * nm);
+    const Fq mz = -z;
+    host_blocks(nm, workers, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            jobs[2].gi[2 * i] = (uint32_t)(nm + i), jobs[2].gs[2 * i] = (z * yi[i] + zpow[i / n] * vec_2n[i % n]) * yinv[i];
+            jobs[2].gi[2 * i + 1] = (uint32_t)i, jobs[2].gs[2 * i + 1] = mz;
+        }
+    });
     jobs[2].gen(iH, -pf.miu);
     jobs[2].gen(iG, pf.tx * xu);
     jobs[2].extra(pf.A, ONE);
@@ -1298,10 +1306,13 @@ int bp_rangeproof_verify(bp_ctx* ctx, const bp_gens* gens, int n_bits, int m, co
         chal_ok = ipa_challenges(pf.ipa, ux, xs, xinv) == BP_OK;
         if (chal_ok) {
             std::vector<Fq> s = s_vector(xs, xinv, nm);
-            for (size_t i = 0; i < nm; i++) {
-                jobs[3].gen(i, s[i] * pf.ipa.a);
-                jobs[3].gen(nm + i, s[nm - 1 - i] * pf.ipa.b * yinv[i]);  // :312-317 (s_i^-1 = s_{nm-1-i})
-            }
+            job_slots(jobs[3], 2 * nm);
+            host_blocks(nm, workers, [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; i++) {
+                    jobs[3].gi[2 * i] = (uint32_t)i, jobs[3].gs[2 * i] = s[i] * pf.ipa.a;
+                    jobs[3].gi[2 * i + 1] = (uint32_t)(nm + i), jobs[3].gs[2 * i + 1] = s[nm - 1 - i] * pf.ipa.b * yinv[i];  // :312-317 (s_i^-1 = s_{nm-1-i})
+                }
+            });
             for (int j = 0; j < k; j++) jobs[3].extra(pf.ipa.L[j], -(xs[j] * xs[j]));
             for (int j = 0; j < k; j++) jobs[3].extra(pf.ipa.R[j], -(xinv[j] * xinv[j]));
             jobs[3].gen(iG, pf.ipa.a * pf.ipa.b * xu);
