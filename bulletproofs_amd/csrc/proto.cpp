@@ -999,21 +999,38 @@ int bp_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint
     Pt yG;
     jobs.assign(1, FbJob());
     jobs[0].gen(gens->ibase, y);  // Point::generator() * y, not the caller's G
-    RC(fbmsm(ctx, gens, jobs, &yG));  // :126
-    if (yG.is_inf()) return BP_EINVAL;
+    // the powers of y and of y^-1 (hi_tag, :223-233) are computed while the GPU multiplies the generator by y
+    std::vector<Fq> yi(nm), yinv(nm), vec_2n(n), zpow(m + 2);
+    const std::function<void()> y_part = [&]() {
+        if (y.is_zero()) return;
+        const Fq yi1 = y.inv();
+        yi[0] = yinv[0] = ONE;
+        for (size_t i = 1; i < nm; i++) {
+            yi[i] = yi[i - 1] * y;
+            yinv[i] = yinv[i - 1] * yi1;
+        }
+        vec_2n[0] = ONE;
+        for (size_t i = 1; i < n; i++) vec_2n[i] = vec_2n[i - 1] + vec_2n[i - 1];
+    };
+    RC(fbmsm(ctx, gens, jobs, &yG, false, &y_part));  // :126
+    if (yG.is_inf() || y.is_zero()) return BP_EINVAL;
     Fq z = Transcript().point(yG.b).result_scalar();  // :127
-    std::vector<Fq> yi(nm), vec_2n(n), zpow(m + 2);
-    yi[0] = ONE;
-    for (size_t i = 1; i < nm; i++) yi[i] = yi[i - 1] * y;
-    vec_2n[0] = ONE;
-    for (size_t i = 1; i < n; i++) vec_2n[i] = vec_2n[i - 1] + vec_2n[i - 1];
     for (int j = 0; j < m; j++) zpow[j] = z.pow(2 + (uint64_t)j);  // z^(2+j)
+    const bool workers = tl_batcher == nullptr;
+    std::mutex sum_mu;
     Fq t1, t2;
-    for (size_t i = 0; i < nm; i++) {
-        t2 = t2 + SR[i] * yi[i] * SL[i];  // :135-137
-        Fq zj2k = zpow[i / n] * vec_2n[i % n];
-        t1 = t1 + SL[i] * ((aR[i] + z) * yi[i]) + (aL[i] - z) * (SR[i] * yi[i]) + zj2k * SL[i];  // :145-162
-    }
+    host_blocks(nm, workers, [&](size_t lo, size_t hi) {  // block sums, added under a lock (the field's addition commutes)
+        Fq b1, b2;
+        for (size_t i = lo; i < hi; i++) {
+            const Fq sry = SR[i] * yi[i];
+            b2 = b2 + sry * SL[i];  // :135-137
+            Fq zj2k = zpow[i / n] * vec_2n[i % n];
+            b1 = b1 + SL[i] * ((aR[i] + z) * yi[i]) + (aL[i] - z) * sry + zj2k * SL[i];  // :145-162
+        }
+        std::lock_guard<std::mutex> lk(sum_mu);
+        t1 = t1 + b1;
+        t2 = t2 + b2;
+    });
     Pt T12[2];
     jobs.assign(2, FbJob());
     jobs[0].gen(iG, t1);  // T1 = t1 G + tau1 H   (:168)
@@ -1029,23 +1046,23 @@ int bp_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const uint
     Fq miu = rho * x + alpha;                                                                  // :184
     std::vector<Fq> Lp(nm), Rp(nm);
     Fq tx;
-    for (size_t i = 0; i < nm; i++) {
-        Lp[i] = SL[i] * x + (aL[i] - z);                                              // :186-192
-        Rp[i] = yi[i] * ((z + aR[i]) + SR[i] * x) + zpow[i / n] * vec_2n[i % n];      // :194-207
-        tx = tx + Lp[i] * Rp[i];                                                      // :208-211
-    }
+    host_blocks(nm, workers, [&](size_t lo, size_t hi) {
+        Fq bx;
+        for (size_t i = lo; i < hi; i++) {
+            Lp[i] = SL[i] * x + (aL[i] - z);                                              // :186-192
+            Rp[i] = yi[i] * ((z + aR[i]) + SR[i] * x) + zpow[i / n] * vec_2n[i % n];      // :194-207
+            bx = bx + Lp[i] * Rp[i];                                                      // :208-211
+        }
+        std::lock_guard<std::mutex> lk(sum_mu);
+        tx = tx + bx;
+    });
     Fq xu = Transcript().scalar(tau_x).scalar(miu).scalar(tx).result_scalar();  // :214-218
     Pt Gx;
     jobs.assign(1, FbJob());
     jobs[0].gen(iG, xu);
     RC(fbmsm(ctx, gens, jobs, &Gx));  // :219
     if (Gx.is_inf()) return BP_EINVAL;
-    // hi_tag = y^-i h_i   (:223-233)
-    std::vector<Fq> yinv(nm);
-    Fq yi1 = y.is_zero() ? ZERO : y.inv();
-    if (y.is_zero()) return BP_EINVAL;
-    yinv[0] = ONE;
-    for (size_t i = 1; i < nm; i++) yinv[i] = yinv[i - 1] * yi1;
+    // hi_tag = y^-i h_i   (:223-233): yinv, computed above
     Ipa ipa;
     if (ctx->proto_path == 1) {  // reference-structured rounds: materialised hi_tag, bases folded every round
         RC(ctx->proto[4].reserve(nm * sizeof(affine_mem)));
