@@ -585,6 +585,24 @@ static void job_slots(FbJob& j, size_t nm) {
     j.gs.resize(nm);
 }
 
+// sum_i a_i b_i y^(i+1) (weighted_inner_product.rs:518-536) in blocks on the host workers: a block starts its power of y by
+// exponentiation and adds its sum under a lock
+Fq weighted_inner_product_par(const Fq* a, const Fq* b, size_t n, const Fq& y, bool workers) {
+    if (!workers || n < 512) return weighted_inner_product(a, b, n, y);
+    std::mutex mu;
+    Fq out;
+    host_blocks(n, true, [&](size_t lo, size_t hi) {
+        Fq sum, yp = y.pow(lo + 1);
+        for (size_t i = lo; i < hi; i++) {
+            sum = sum + a[i] * b[i] * yp;
+            yp = yp * y;
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        out = out + sum;
+    });
+    return out;
+}
+
 // InnerProductArg::prove (:36-169) without ever folding a base: after j rounds the folded bases are
 //   G^(j)[i] = sum_{t = i mod n'} cG[t] g_t,   H^(j)[i] = sum_{t = i mod n'} cH[t] h_t     (n' = nm / 2^j)
 // with cG/cH products of the challenges (G_new = x^-1 G_L + x G_R, :140-146: indices in the lower half of
@@ -1362,7 +1380,7 @@ struct PlusScalars {
     std::vector<Fq> y_pow, d, z2m;  // y^(i+1); d_i; z^(2(j+1))
     Fq y_nm1, zeta;                 // y^(nm+1); zeta(y, z)
 };
-PlusScalars plus_common(size_t n, size_t m, const Fq& y, const Fq& z) {  // range_proof_wip.rs:175-224 / 428-455 / 521-531
+PlusScalars plus_common(size_t n, size_t m, const Fq& y, const Fq& z, bool want_zeta = true) {  // range_proof_wip.rs:175-224 / 428-455 / 521-531
     size_t nm = n * m;
     PlusScalars o;
     Fq zsq = z * z;
@@ -1379,7 +1397,8 @@ PlusScalars plus_common(size_t n, size_t m, const Fq& y, const Fq& z) {  // rang
     for (size_t i = 0; i < nm; i++) o.d[i] = v2[i % n] * o.z2m[i / n];
     o.y_nm1 = o.y_pow[nm - 1] * y;
     Fq zmz2 = z - zsq, zy = z * o.y_nm1;
-    for (size_t i = 0; i < nm; i++) o.zeta = o.zeta + (zmz2 * o.y_pow[i] - o.d[i] * zy);
+    if (want_zeta)  // (the verifiers' constant; the prover does not use it)
+        for (size_t i = 0; i < nm; i++) o.zeta = o.zeta + (zmz2 * o.y_pow[i] - o.d[i] * zy);
     return o;
 }
 
@@ -1474,11 +1493,13 @@ int wip_prove_fixed(bp_ctx* ctx, const bp_gens* g, const Pt& gh, const Pt& hh, s
         const size_t h = n / 2;
         Fq yn = y.pow(h), yninv = yinv.pow(h);  // powers_y[n-1], powers_yinv[n-1]  (:71-76, :91, :94)
         std::vector<Fq> yn_aR(h), yninv_aL(h);
-        for (size_t i = 0; i < h; i++) {
-            yn_aR[i] = yn * a[h + i];
-            yninv_aL[i] = yninv * a[i];
-        }
-        Fq cL = weighted_inner_product(&a[0], &b[h], h, y), cR = weighted_inner_product(&yn_aR[0], &b[0], h, y);
+        host_blocks(h, threads, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                yn_aR[i] = yn * a[h + i];
+                yninv_aL[i] = yninv * a[i];
+            }
+        });
+        Fq cL = weighted_inner_product_par(&a[0], &b[h], h, y, threads), cR = weighted_inner_product_par(&yn_aR[0], &b[0], h, y, threads);
         Fq dL = tp.next();  // :106
         Fq dR = tp.next();  // :134
         if (!tp.ok) return BP_EINVAL;
@@ -1514,10 +1535,12 @@ int wip_prove_fixed(bp_ctx* ctx, const bp_gens* g, const Pt& gh, const Pt& hh, s
         if (x.is_zero()) return BP_EINVAL;
         Fq xi = x.inv(), xsq = x * x, xyn = x * yninv;
         std::vector<Fq> an(h), bn(h);
-        for (size_t i = 0; i < h; i++) {
-            an[i] = a[i] * x + yn_aR[i] * xi;  // :164-170
-            bn[i] = b[h + i] * x + b[i] * xi;  // :173-179
-        }
+        host_blocks(h, threads, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                an[i] = a[i] * x + yn_aR[i] * xi;  // :164-170
+                bn[i] = b[h + i] * x + b[i] * xi;  // :173-179
+            }
+        });
         alpha = alpha + xsq * dL + (xi * xi) * dR;  // :182-185 (x^-2 = (x^-1)^2: no second exponentiation)
         pend = true;  // cG[t] *= (lower ? x^-1 : x y^-n'), cH[t] *= (lower ? x : x^-1): applied by the next pass over t (:187-204)
         px = x;
@@ -1642,7 +1665,7 @@ int bp_wip_rangeproof_prove(bp_ctx* ctx, const bp_gens* gens, int n_bits, const 
     RC(fbmsm(ctx, gens, jobs, &yG));
     if (yG.is_inf()) return BP_EINVAL;
     Fq z = Transcript().point(A.b).point(yG.b).result_scalar();  // :171
-    PlusScalars ps = plus_common(n, m, y, z);
+    PlusScalars ps = plus_common(n, m, y, z, false);
     Fq ip_blinding;
     for (int j = 0; j < m; j++) ip_blinding = ip_blinding + Fq::from_be(blindings_be + 32 * j) * ps.z2m[j];  // :205-207
     Fq scalar_H = ip_blinding * ps.y_nm1;
